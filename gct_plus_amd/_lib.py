@@ -1,0 +1,86 @@
+"""ctypes binding of libgctplus_hip.so (C ABI: include/gctplus_hip.h).
+
+The library is mandatory: there is no CPU / eager-PyTorch fallback.  `load()` raises
+if the shared object is missing or does not export every declared symbol.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgctplus_hip.so")
+
+P, I64, I32, F32, U64, U32 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_uint32
+
+# name -> (restype, [argtypes])   -- mirrors include/gctplus_hip.h one to one
+SIGNATURES = {
+    "gct_version": (I32, []),
+    "gct_last_error": (C.c_char_p, []),
+    "gct_wgrad_ws_bytes": (I64, [I64, I64, I64]),
+    "gct_rowred_ws_bytes": (I64, [I64, I64]),
+    "gct_embed_ws_bytes": (I64, [I32, I32, I32, I32]),
+    "gct_norm_fwd": (I32, [P, P, P, P, P, P, I64, I32, F32, P]),
+    "gct_norm_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, I64, I32, F32, P]),
+    "gct_embed_pe_fwd": (I32, [P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, U64, U32, P]),
+    "gct_embed_pe_bwd": (I32, [P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, U64, U32, P]),
+    "gct_linear_fwd": (I32, [P, I64, I64, I32, P, P, P, I64, P, P, P, I32, I32, P, P, P, I64,
+                             I32, P, P, F32, U64, U32, P]),
+    "gct_linear_dgrad": (I32, [P, P, P, I64, I64, I32, I32, P, P, P, I64, I32, P, I64, I32, P,
+                               F32, U64, U32, P]),
+    "gct_linear_wgrad": (I32, [P, P, P, I64, I64, I32, I32, P, I64, I32, P, P, P, I64, P, P, P,
+                               P, P]),
+    "gct_dropout_bwd": (I32, [P, P, I64, I32, F32, U64, U32, P]),
+    "gct_attn_fwd": (I32, [P, I64, P, I64, P, I64, P, I64, I64, P, I64, P, P, I32, I32, I32, I32,
+                           I32, F32, F32, U64, U32, P]),
+    "gct_attn_bwd": (I32, [P, I64, P, I64, P, I64, P, I64, I64, P, P, I64, P, P, P, I64, P, I64,
+                           P, I64, I32, I32, I32, I32, I32, F32, F32, U64, U32, P]),
+    "gct_reparam_fwd": (I32, [P, P, P, P, P, I64, U64, U32, P]),
+    "gct_reparam_bwd": (I32, [P, P, P, P, P, P, P, I64, P]),
+    "gct_kld_fwd": (I32, [P, P, P, P, I64, P]),
+    "gct_kld_bwd": (I32, [P, P, P, P, P, I64, P]),
+    "gct_ce_fwd": (I32, [P, P, P, P, I64, I32, I64, P]),
+    "gct_ce_bwd": (I32, [P, P, P, P, I64, I32, I64, P]),
+    "gct_adam_step": (I32, [P, P, P, P, I64, F32, F32, F32, F32, I64, F32, P]),
+    "gct_copy_rows": (I32, [P, I64, I64, P, I64, I64, I64, I64, I32, I32, P]),
+    "gct_small_linear_fwd": (I32, [P, P, P, P, I32, I32, I32, P]),
+    "gct_small_linear_bwd": (I32, [P, P, P, P, I32, I32, I32, P]),
+    "gct_reduce_slabs": (I32, [P, I32, I64, P, I64, I32, P]),
+    "gct_add": (I32, [P, P, P, I64, P]),
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class GctError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; hard error if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GctError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C gct_plus_amd/csrc`). gct_plus_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise GctError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gct_version() != ABI_VERSION:
+        raise GctError(f"ABI mismatch: library {lib.gct_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().gct_last_error().decode("utf-8", "replace")
+        raise GctError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,442 @@
+// K4: multi-head attention core, forward and backward.
+// Reference: Model/sublayers.py:29-41 attention():  softmax(q k^T / sqrt(dk) masked_fill(mask==0,
+// -1e9)) -> dropout on the probabilities -> . v ; head split/merge of sublayers.py:64-69 is
+// folded into the addressing (q/k/v are read in place from the fused projection buffer, o is
+// written heads-merged).
+//
+// Machine mapping (gfx950): L <= 128 and dk <= 64, so a whole (batch, head) problem lives in one
+// workgroup's LDS: Q (pre-scaled), K, V [L][dk+4] fp32 plus one flag byte per (q,k) holding
+// {in-range, not-masked, dropout-keep}.  All products run on v_mfma_f32_16x16x4_f32 (exact fp32).
+// The score tile is computed TRANSPOSED (S^T = K Q^T): its accumulator layout then has the key
+// index on the registers and the query on the lane, which is exactly the B-operand layout the
+// following P.V product (summing over keys) needs -- probabilities never leave registers and
+// never touch HBM; a softmax row is reduced over 4 regs x tiles in-lane plus two shuffles.
+// Backward recomputes probabilities from the saved log-sum-exp (no [B,H,L,L] tensor is stored):
+//   pass A (query-tile owners):  S^T, dP^T -> dS^T -> dQ
+//   pass B (key-tile owners)  :  S, dP -> P_drop, dS -> dV, dK   (sums over the register index)
+// Roofline: HBM-bound on q,k,v,o (+ their gradients); 4.L.d flop/token ~ 3 % of the step.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NT_MAX = 8;  // L <= 128
+
+struct AttnArgs {
+  const float *q, *k, *v;
+  int64_t ldq, ldk, ldv;
+  const uint8_t* mask;
+  int64_t mask_sb, mask_sq;
+  float* o;
+  int64_t ldo;
+  float* lse;
+  float* probs;
+  // backward
+  const float *o_in, *dout, *lse_in;
+  float *dq, *dk, *dv;
+  int64_t lddq, lddk, lddv;
+  int B, H, Lq, Lk;
+  float scale, keep_scale;
+  uint32_t thr;
+  GctRng rng;
+};
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// stage rows [0,L) of a [B][L][ld] head slice into LDS [LP][SD], zero padded, optional scale
+template <int DK>
+__device__ __forceinline__ void stage(float* dst, const float* src, int64_t ld, int b, int h, int L,
+                                      int LP, float scale, int tid) {
+  constexpr int SD = DK + 4, C = DK / 4;
+  for (int idx = tid; idx < LP * C; idx += 256) {
+    const int r = idx / C, c = idx - r * C;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < L) {
+      v = *reinterpret_cast<const float4*>(src + ((int64_t)b * L + r) * ld + h * DK + c * 4);
+      v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+    }
+    *reinterpret_cast<float4*>(dst + r * SD + c * 4) = v;
+  }
+}
+
+// flags[q][k]: bit2 in range, bit0 not masked, bit1 dropout keep. One Philox call per (q, 4 keys).
+__device__ __forceinline__ void build_flags(uint32_t* flags32, const AttnArgs& a, int b, int h,
+                                            int LQP, int LKP, int tid) {
+  const int KG = LKP / 4;
+  for (int idx = tid; idx < LQP * KG; idx += 256) {
+    const int q = idx / KG, kg = idx - q * KG;
+    uint32_t w = 0;
+    if (q < a.Lq) {
+      uint4 bits = make_uint4(~0u, ~0u, ~0u, ~0u);
+      if (a.thr)
+        bits = gct_philox(a.rng, (uint32_t)(((int64_t)b * a.H + h) * a.Lq + q), (uint32_t)kg,
+                          0xA4093822u, 0x299F31D0u);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = kg * 4 + e;
+        uint32_t f = 0;
+        if (k < a.Lk) {
+          f = 4u;
+          const uint8_t mv = a.mask ? a.mask[(int64_t)b * a.mask_sb + (int64_t)q * a.mask_sq + k] : 1;
+          if (mv) f |= 1u;
+          if (gct_pick(bits, e) >= a.thr) f |= 2u;
+        }
+        w |= f << (8 * e);
+      }
+    }
+    flags32[idx] = w;
+  }
+}
+
+__device__ __forceinline__ float score_of(float s, uint32_t f) {
+  return (f & 4u) ? ((f & 1u) ? s : -1e9f) : -INFINITY;
+}
+
+// ------------------------------------------------------------------------------ forward
+template <int NDT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+  constexpr int DK = 16 * NDT, SD = DK + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int LQP = (a.Lq + 15) & ~15, LKP = (a.Lk + 15) & ~15, nkt = LKP / 16, KG = LKP / 4;
+  float* Qs = smem;
+  float* Ks = Qs + LQP * SD;
+  float* Vs = Ks + LKP * SD;
+  uint32_t* flags32 = reinterpret_cast<uint32_t*>(Vs + LKP * SD);
+  stage<DK>(Qs, a.q, a.ldq, b, h, a.Lq, LQP, a.scale, tid);
+  stage<DK>(Ks, a.k, a.ldk, b, h, a.Lk, LKP, 1.0f, tid);
+  stage<DK>(Vs, a.v, a.ldv, b, h, a.Lk, LKP, 1.0f, tid);
+  build_flags(flags32, a, b, h, LQP, LKP, tid);
+  __syncthreads();
+
+  for (int u = wave; u < LQP / 16; u += 4) {
+    const int q = 16 * u + c16;
+    f32x4 sacc[NT_MAX];
+#pragma unroll
+    for (int t = 0; t < NT_MAX; ++t) sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // S^T[k][q] = sum_d K[k][d] * Qs[q][d]
+#pragma unroll 2
+    for (int s = 0; s < DK / 4; ++s) {
+      const float bq = Qs[q * SD + 4 * s + g];
+#pragma unroll
+      for (int t = 0; t < NT_MAX; ++t)
+        if (t < nkt) sacc[t] = mfma16(Ks[(16 * t + c16) * SD + 4 * s + g], bq, sacc[t]);
+    }
+    // mask + softmax over keys (regs x tiles in-lane, then lanes l^16, l^32)
+    uint32_t fw[NT_MAX];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT_MAX; ++t)
+      if (t < nkt) {
+        fw[t] = flags32[q * KG + 4 * t + g];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sv = score_of(sacc[t][r], (fw[t] >> (8 * r)) & 0xffu);
+          sacc[t][r] = sv;
+          m = fmaxf(m, sv);
+        }
+      }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    if (m == -INFINITY) m = 0.f;
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT_MAX; ++t)
+      if (t < nkt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = expf(sacc[t][r] - m);
+          sacc[t][r] = e;
+          l += e;
+        }
+      }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    const int64_t grow = ((int64_t)b * a.H + h) * a.Lq + q;
+    if (g == 0 && q < a.Lq) a.lse[grow] = m + logf(l);
+#pragma unroll
+    for (int t = 0; t < NT_MAX; ++t)
+      if (t < nkt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = sacc[t][r] * inv;
+          const int k = 16 * t + 4 * g + r;
+          if (a.probs && q < a.Lq && k < a.Lk) a.probs[grow * a.Lk + k] = p;
+          sacc[t][r] = ((fw[t] >> (8 * r)) & 2u) ? p * a.keep_scale : 0.f;
+        }
+      }
+    // O^T[d][q] = sum_k V[k][d] * Pdrop^T[k][q]
+    f32x4 oacc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT_MAX; ++t)
+      if (t < nkt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float bp = sacc[t][r];
+          const float* vrow = Vs + (16 * t + 4 * g + r) * SD + c16;
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) oacc[dt] = mfma16(vrow[16 * dt], bp, oacc[dt]);
+        }
+      }
+    if (q < a.Lq) {
+      float* orow = a.o + ((int64_t)b * a.Lq + q) * a.ldo + h * DK + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+        *reinterpret_cast<float4*>(orow + 16 * dt) =
+            make_float4(oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------- backward
+template <int NDT>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
+  constexpr int DK = 16 * NDT, SD = DK + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int LQP = (a.Lq + 15) & ~15, LKP = (a.Lk + 15) & ~15, nkt = LKP / 16, nqt = LQP / 16,
+            KG = LKP / 4;
+  float* Qs = smem;               // scaled by `scale`
+  float* Ks = Qs + LQP * SD;
+  float* Vs = Ks + LKP * SD;
+  float* dOs = Vs + LKP * SD;
+  float* lse_s = dOs + LQP * SD;  // [LQP]
+  float* del_s = lse_s + LQP;     // [LQP]
+  uint32_t* flags32 = reinterpret_cast<uint32_t*>(del_s + LQP);
+  const uint8_t* flags8 = reinterpret_cast<const uint8_t*>(flags32);
+  stage<DK>(Qs, a.q, a.ldq, b, h, a.Lq, LQP, a.scale, tid);
+  stage<DK>(Ks, a.k, a.ldk, b, h, a.Lk, LKP, 1.0f, tid);
+  stage<DK>(Vs, a.v, a.ldv, b, h, a.Lk, LKP, 1.0f, tid);
+  stage<DK>(dOs, a.dout, a.ldo, b, h, a.Lq, LQP, 1.0f, tid);
+  build_flags(flags32, a, b, h, LQP, LKP, tid);
+  // delta[q] = sum_d dO[q][d] * O[q][d]  (16 lanes per row)
+  for (int r0 = tid >> 4; r0 < LQP; r0 += 16) {
+    float acc = 0.f;
+    if (r0 < a.Lq) {
+      const float* orow = a.o_in + ((int64_t)b * a.Lq + r0) * a.ldo + h * DK;
+      const float* drow = a.dout + ((int64_t)b * a.Lq + r0) * a.ldo + h * DK;
+      for (int c = (tid & 15) * 4; c < DK; c += 64) {
+        const float4 x = *reinterpret_cast<const float4*>(orow + c);
+        const float4 y = *reinterpret_cast<const float4*>(drow + c);
+        acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+      }
+    }
+    acc += __shfl_xor(acc, 8, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 1, 64);
+    if ((tid & 15) == 0) {
+      del_s[r0] = acc;
+      lse_s[r0] = r0 < a.Lq ? a.lse_in[((int64_t)b * a.H + h) * a.Lq + r0] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  // ---- pass A: dQ. Wave owns query tile u; key index on registers.
+  for (int u = wave; u < nqt; u += 4) {
+    const int q = 16 * u + c16;
+    f32x4 sacc[NT_MAX], pacc[NT_MAX];
+#pragma unroll
+    for (int t = 0; t < NT_MAX; ++t) {
+      sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      pacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 2
+    for (int s = 0; s < DK / 4; ++s) {
+      const float bq = Qs[q * SD + 4 * s + g];
+      const float bd = dOs[q * SD + 4 * s + g];
+#pragma unroll
+      for (int t = 0; t < NT_MAX; ++t)
+        if (t < nkt) {
+          sacc[t] = mfma16(Ks[(16 * t + c16) * SD + 4 * s + g], bq, sacc[t]);  // S^T
+          pacc[t] = mfma16(Vs[(16 * t + c16) * SD + 4 * s + g], bd, pacc[t]);  // dP^T
+        }
+    }
+    const float lse = lse_s[q], del = del_s[q];
+#pragma unroll
+    for (int t = 0; t < NT_MAX; ++t)
+      if (t < nkt) {
+        const uint32_t w = flags32[q * KG + 4 * t + g];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t f = (w >> (8 * r)) & 0xffu;
+          const float p = (f & 4u) ? expf(score_of(sacc[t][r], f) - lse) : 0.f;
+          const float dpd = (f & 2u) ? pacc[t][r] * a.keep_scale : 0.f;
+          sacc[t][r] = (f & 1u) ? p * (dpd - del) : 0.f;  // dS^T (masked_fill passes no grad)
+        }
+      }
+    f32x4 qacc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) qacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT_MAX; ++t)
+      if (t < nkt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float bs = sacc[t][r];
+          const float* krow = Ks + (16 * t + 4 * g + r) * SD + c16;
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) qacc[dt] = mfma16(krow[16 * dt], bs, qacc[dt]);
+        }
+      }
+    if (q < a.Lq) {
+      float* drow = a.dq + ((int64_t)b * a.Lq + q) * a.lddq + h * DK + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+        *reinterpret_cast<float4*>(drow + 16 * dt) =
+            make_float4(qacc[dt][0] * a.scale, qacc[dt][1] * a.scale, qacc[dt][2] * a.scale,
+                        qacc[dt][3] * a.scale);
+    }
+  }
+
+  // ---- pass B: dK, dV. Wave owns key tile t; query index on registers.
+  for (int t = wave; t < nkt; t += 4) {
+    const int k = 16 * t + c16;
+    f32x4 vacc[NDT], kacc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      vacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      kacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 1
+    for (int u = 0; u < nqt; ++u) {
+      f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, pa = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int s = 0; s < DK / 4; ++s) {
+        sa = mfma16(Qs[(16 * u + c16) * SD + 4 * s + g], Ks[k * SD + 4 * s + g], sa);   // S[q][k]
+        pa = mfma16(dOs[(16 * u + c16) * SD + 4 * s + g], Vs[k * SD + 4 * s + g], pa);  // dP[q][k]
+      }
+      float pd[4], ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qq = 16 * u + 4 * g + r;
+        const uint32_t f = flags8[qq * LKP + k];
+        const float p = (f & 4u) ? expf(score_of(sa[r], f) - lse_s[qq]) : 0.f;
+        const float dpd = (f & 2u) ? pa[r] * a.keep_scale : 0.f;
+        pd[r] = (f & 2u) ? p * a.keep_scale : 0.f;
+        ds[r] = (f & 1u) ? p * (dpd - del_s[qq]) : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* dorow = dOs + (16 * u + 4 * g + r) * SD + c16;
+        const float* qrow = Qs + (16 * u + 4 * g + r) * SD + c16;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          vacc[dt] = mfma16(dorow[16 * dt], pd[r], vacc[dt]);  // dV^T[d][k] += dO[q][d] Pd[q][k]
+          kacc[dt] = mfma16(qrow[16 * dt], ds[r], kacc[dt]);   // dK^T[d][k] += Qs[q][d] dS[q][k]
+        }
+      }
+    }
+    if (k < a.Lk) {
+      float* vrow = a.dv + ((int64_t)b * a.Lk + k) * a.lddv + h * DK + 4 * g;
+      float* krow = a.dk + ((int64_t)b * a.Lk + k) * a.lddk + h * DK + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        *reinterpret_cast<float4*>(vrow + 16 * dt) =
+            make_float4(vacc[dt][0], vacc[dt][1], vacc[dt][2], vacc[dt][3]);
+        *reinterpret_cast<float4*>(krow + 16 * dt) =
+            make_float4(kacc[dt][0], kacc[dt][1], kacc[dt][2], kacc[dt][3]);
+      }
+    }
+  }
+}
+
+template <typename K>
+int ensure_lds(K kernel, size_t lds, bool* done) {
+  if (lds <= 64 * 1024 || *done) return GCT_OK;
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024);
+  if (e != hipSuccess) {
+    gct_set_error("attention: cannot opt in to 160 KB LDS: %s", hipGetErrorString(e));
+    return GCT_ERR_HIP;
+  }
+  *done = true;
+  return GCT_OK;
+}
+
+int check_common(const char* who, const float* q, int64_t ldq, const float* k, int64_t ldk,
+                 const float* v, int64_t ldv, int B, int H, int Lq, int Lk, int dk, float p) {
+  GCT_CHECK_ARG(q && k && v && B >= 0 && H > 0 && Lq > 0 && Lk > 0, "%s: bad args", who);
+  GCT_CHECK_ARG(dk == 16 || dk == 32 || dk == 64, "%s: head dim %d unsupported (16/32/64)", who, dk);
+  GCT_CHECK_ARG(Lq <= 16 * NT_MAX && Lk <= 16 * NT_MAX, "%s: sequence length > %d unsupported", who,
+                16 * NT_MAX);
+  GCT_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && gct_aligned16(q) &&
+                    gct_aligned16(k) && gct_aligned16(v),
+                "%s: q/k/v must be 16-B aligned with ld %% 4 == 0", who);
+  GCT_CHECK_ARG(p >= 0.f && p < 1.f, "%s: dropout p out of range", who);
+  return GCT_OK;
+}
+
+}  // namespace
+
+extern "C" int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk,
+                            const float* v, int64_t ldv, const uint8_t* mask, int64_t mask_sb,
+                            int64_t mask_sq, float* o, int64_t ldo, float* lse, float* probs, int B,
+                            int H, int Lq, int Lk, int dk, float scale, float p, uint64_t seed,
+                            uint32_t site, void* stream) {
+  int rc = check_common("attn_fwd", q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dk, p);
+  if (rc) return rc;
+  GCT_CHECK_ARG(o && lse && ldo % 4 == 0 && gct_aligned16(o), "attn_fwd: bad output");
+  if (B == 0) return GCT_OK;
+  AttnArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
+  a.mask = mask; a.mask_sb = mask_sb; a.mask_sq = mask_sq;
+  a.o = o; a.ldo = ldo; a.lse = lse; a.probs = probs;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
+  a.thr = gct_drop_threshold(p); a.keep_scale = 1.0f / (1.0f - p); a.rng = gct_rng_make(seed, site);
+  const int LQP = (Lq + 15) & ~15, LKP = (Lk + 15) & ~15, SD = dk + 4;
+  const size_t lds = (size_t)(LQP + 2 * LKP) * SD * 4 + (size_t)LQP * LKP;
+  dim3 grid((unsigned)(B * H)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  static bool f4 = false, f2 = false, f1 = false;
+  GCT_CHECK_ARG(lds <= 160 * 1024, "attn_fwd: needs %zu B of LDS", lds);
+  if (dk == 64) { if ((rc = ensure_lds(attn_fwd_kernel<4>, lds, &f4))) return rc; hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, block, lds, st, a); }
+  else if (dk == 32) { if ((rc = ensure_lds(attn_fwd_kernel<2>, lds, &f2))) return rc; hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, lds, st, a); }
+  else { if ((rc = ensure_lds(attn_fwd_kernel<1>, lds, &f1))) return rc; hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, lds, st, a); }
+  GCT_LAUNCH_CHECK("attn_fwd");
+  return GCT_OK;
+}
+
+extern "C" int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk,
+                            const float* v, int64_t ldv, const uint8_t* mask, int64_t mask_sb,
+                            int64_t mask_sq, const float* o, const float* dout, int64_t ldo,
+                            const float* lse, float* delta, float* dq, int64_t lddq, float* dk_,
+                            int64_t lddk, float* dv, int64_t lddv, int B, int H, int Lq, int Lk,
+                            int dk, float scale, float p, uint64_t seed, uint32_t site,
+                            void* stream) {
+  (void)delta;
+  int rc = check_common("attn_bwd", q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dk, p);
+  if (rc) return rc;
+  GCT_CHECK_ARG(o && dout && lse && dq && dk_ && dv, "attn_bwd: null pointer");
+  GCT_CHECK_ARG(ldo % 4 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 &&
+                    gct_aligned16(o) && gct_aligned16(dout) && gct_aligned16(dq) &&
+                    gct_aligned16(dk_) && gct_aligned16(dv),
+                "attn_bwd: buffers must be 16-B aligned with ld %% 4 == 0");
+  if (B == 0) return GCT_OK;
+  AttnArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
+  a.mask = mask; a.mask_sb = mask_sb; a.mask_sq = mask_sq;
+  a.o_in = o; a.dout = dout; a.ldo = ldo; a.lse_in = lse;
+  a.dq = dq; a.dk = dk_; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
+  a.thr = gct_drop_threshold(p); a.keep_scale = 1.0f / (1.0f - p); a.rng = gct_rng_make(seed, site);
+  const int LQP = (Lq + 15) & ~15, LKP = (Lk + 15) & ~15, SD = dk + 4;
+  const size_t lds = (size_t)(2 * LQP + 2 * LKP) * SD * 4 + (size_t)LQP * 8 + (size_t)LQP * LKP;
+  dim3 grid((unsigned)(B * H)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  static bool f4 = false, f2 = false, f1 = false;
+  GCT_CHECK_ARG(lds <= 160 * 1024, "attn_bwd: needs %zu B of LDS", lds);
+  if (dk == 64) { if ((rc = ensure_lds(attn_bwd_kernel<4>, lds, &f4))) return rc; hipLaunchKernelGGL(attn_bwd_kernel<4>, grid, block, lds, st, a); }
+  else if (dk == 32) { if ((rc = ensure_lds(attn_bwd_kernel<2>, lds, &f2))) return rc; hipLaunchKernelGGL(attn_bwd_kernel<2>, grid, block, lds, st, a); }
+  else { if ((rc = ensure_lds(attn_bwd_kernel<1>, lds, &f1))) return rc; hipLaunchKernelGGL(attn_bwd_kernel<1>, grid, block, lds, st, a); }
+  GCT_LAUNCH_CHECK("attn_bwd");
+  return GCT_OK;
+}

@@ -1,0 +1,142 @@
+// K1: token embedding lookup + property-token concat + positional encoding + dropout.
+// Reference: Model/modules.py:108-110 (nn.Embedding), :134-144 (x*sqrt(d) + pe, dropout),
+// Model/vaetf.py:35-39 / Model/cvaetf.py:38-41 (cond rows concatenated in FRONT, they get PE too).
+// HBM-bound: the table (<= 31 rows x 2 KB) and pe stay in L2; traffic = the [B*L][d] output.
+// Backward: per-vocab-row segmented reduction in LDS (V <= 64 rows), partial slabs per row
+// chunk, deterministic slab reduction -- no atomics.
+#include "common.h"
+
+namespace {
+
+// thread = (4 consecutive rows) x (1 column); lanes run along columns (coalesced).
+__global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const int64_t* __restrict__ tok,
+                                                           const float* __restrict__ table,
+                                                           const float* __restrict__ cond,
+                                                           const float* __restrict__ pe, float* out,
+                                                           int B, int S, int n_c, int d, int vocab,
+                                                           float scale, uint32_t thr,
+                                                           float keep_scale, GctRng rng) {
+  const int L = S + n_c;
+  const int64_t rows = (int64_t)B * L;
+  const int64_t total = ((rows + 3) / 4) * d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t gq = i / d;
+    const int col = (int)(i - gq * d);
+    uint4 bits = make_uint4(~0u, ~0u, ~0u, ~0u);
+    if (thr) bits = gct_drop_bits(rng, (uint32_t)gq, (uint32_t)col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t row = gq * 4 + e;
+      if (row >= rows) break;
+      const int b = (int)(row / L), l = (int)(row - (int64_t)b * L);
+      float v;
+      if (l < n_c) {
+        v = cond[((int64_t)b * n_c + l) * d + col];
+      } else {
+        int64_t t = tok[(int64_t)b * S + (l - n_c)];
+        t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);  // clamp: never fault on a bad id
+        v = table[t * d + col];
+      }
+      v = v * scale + pe[(int64_t)l * d + col];
+      v = gct_pick(bits, e) >= thr ? v * keep_scale : 0.f;
+      out[row * d + col] = v;
+    }
+  }
+}
+
+// grid = (ceil(d/256), chunks); block = 256 columns; LDS acc[vocab][256]
+__global__ __launch_bounds__(256) void embed_pe_bwd_kernel(const float* __restrict__ dout,
+                                                           const int64_t* __restrict__ tok,
+                                                           float* dcond, float* partial, int B,
+                                                           int S, int n_c, int d, int vocab,
+                                                           float gscale, uint32_t thr, GctRng rng,
+                                                           int64_t groups_per_chunk) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];  // [vocab][256]
+  const int tx = threadIdx.x, col = blockIdx.x * 256 + tx;
+  for (int v = 0; v < vocab; ++v) acc[v * 256 + tx] = 0.f;
+  const int L = S + n_c;
+  const int64_t rows = (int64_t)B * L, ngroups = (rows + 3) / 4;
+  const int64_t g0 = (int64_t)blockIdx.y * groups_per_chunk;
+  const int64_t g1 = g0 + groups_per_chunk < ngroups ? g0 + groups_per_chunk : ngroups;
+  if (col < d) {
+    for (int64_t gq = g0; gq < g1; ++gq) {
+      uint4 bits = make_uint4(~0u, ~0u, ~0u, ~0u);
+      if (thr) bits = gct_drop_bits(rng, (uint32_t)gq, (uint32_t)col);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t row = gq * 4 + e;
+        if (row >= rows) break;
+        const float g = gct_pick(bits, e) >= thr ? dout[row * d + col] * gscale : 0.f;
+        const int b = (int)(row / L), l = (int)(row - (int64_t)b * L);
+        if (l < n_c) {
+          dcond[((int64_t)b * n_c + l) * d + col] = g;
+        } else {
+          int64_t t = tok[(int64_t)b * S + (l - n_c)];
+          t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+          acc[t * 256 + tx] += g;
+        }
+      }
+    }
+    float* p = partial + (int64_t)blockIdx.y * vocab * d;
+    for (int v = 0; v < vocab; ++v) p[(int64_t)v * d + col] = acc[v * 256 + tx];
+  }
+}
+
+inline int embed_chunks(int64_t rows) {
+  int64_t c = (rows / 4 + 63) / 64;
+  if (c > 256) c = 256;
+  if (c < 1) c = 1;
+  return (int)c;
+}
+
+}  // namespace
+
+extern "C" int64_t gct_embed_ws_bytes(int B, int S, int d, int vocab) {
+  return (int64_t)embed_chunks((int64_t)B * (S + 8)) * vocab * d * (int64_t)sizeof(float) + 256;
+}
+
+extern "C" int gct_embed_pe_fwd(const int64_t* tok, const float* table, const float* cond,
+                                const float* pe, float* out, int B, int S, int n_c, int d,
+                                int vocab, float scale, float p, uint64_t seed, uint32_t site,
+                                void* stream) {
+  GCT_CHECK_ARG(tok && table && pe && out && B >= 0 && S > 0 && d > 0 && vocab > 0 && n_c >= 0,
+                "embed_pe_fwd: bad args");
+  GCT_CHECK_ARG(n_c == 0 || cond, "embed_pe_fwd: cond rows requested without a cond buffer");
+  GCT_CHECK_ARG(p >= 0.f && p < 1.f, "embed_pe_fwd: dropout p out of range");
+  if (B == 0) return GCT_OK;
+  const int64_t total = (((int64_t)B * (S + n_c) + 3) / 4) * d;
+  int64_t grid = (total + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                     tok, table, cond, pe, out, B, S, n_c, d, vocab, scale, gct_drop_threshold(p),
+                     1.0f / (1.0f - p), gct_rng_make(seed, site));
+  GCT_LAUNCH_CHECK("embed_pe_fwd");
+  return GCT_OK;
+}
+
+int gct_reduce_slabs_seg(const float* slabs, int nslab, int64_t stride, float* d0, float* d1,
+                         float* d2, int64_t nper_elems, int64_t n, hipStream_t st);
+
+extern "C" int gct_embed_pe_bwd(const float* dout, const int64_t* tok, float* dtable, float* dcond,
+                                float* ws, int B, int S, int n_c, int d, int vocab, float scale,
+                                float p, uint64_t seed, uint32_t site, void* stream) {
+  GCT_CHECK_ARG(dout && tok && dtable && ws && B >= 0 && S > 0 && d > 0 && vocab > 0 && n_c >= 0,
+                "embed_pe_bwd: bad args");
+  GCT_CHECK_ARG(n_c == 0 || dcond, "embed_pe_bwd: dcond missing");
+  GCT_CHECK_ARG(vocab <= 64, "embed_pe_bwd: vocab %d > 64 unsupported (LDS table)", vocab);
+  GCT_CHECK_ARG(p >= 0.f && p < 1.f, "embed_pe_bwd: dropout p out of range");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)B * (S + n_c);
+  const int chunks = embed_chunks((int64_t)B * (S + 8));
+  const int64_t ngroups = (rows + 3) / 4;
+  int64_t gpc = (ngroups + chunks - 1) / chunks;
+  if (gpc < 1) gpc = 1;
+  dim3 grid((unsigned)((d + 255) / 256), (unsigned)chunks);
+  hipLaunchKernelGGL(embed_pe_bwd_kernel, grid, dim3(256), (size_t)vocab * 256 * sizeof(float), st,
+                     dout, tok, dcond, ws, B, S, n_c, d, vocab, scale / (1.0f - p),
+                     gct_drop_threshold(p), gct_rng_make(seed, site), gpc);
+  GCT_LAUNCH_CHECK("embed_pe_bwd");
+  const int64_t n = (int64_t)vocab * d;
+  return gct_reduce_slabs_seg(ws, chunks, n, dtable, nullptr, nullptr, n, n, st);
+}

@@ -1,0 +1,221 @@
+// Deterministic reductions and small utility kernels (all HBM-bound).
+//   gct_reduce_slabs      : dst[i] = sum_s slabs[s][i]     (split-K / partial-sum tails)
+//   gct_colsum            : db[n] = sum_m dY[m][n]         (bias gradients; Linear backward)
+//   gct_add, gct_copy_rows, gct_dropout_bwd
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs,
+                                                           int nslab, int64_t stride, float* d0,
+                                                           float* d1, float* d2, int64_t nper,
+                                                           int64_t n4, int accumulate) {
+  // n4 = number of float4 groups; nper (elements, multiple of 4) selects the destination
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i * 4;
+    float4 a = *reinterpret_cast<const float4*>(slabs + e);
+    for (int s = 1; s < nslab; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(slabs + (int64_t)s * stride + e);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const int q = (int)(e >= nper) + (int)(e >= 2 * nper);
+    float* d = (q == 0 ? d0 : (q == 1 ? d1 : d2)) + (e - q * nper);
+    if (accumulate) {
+      const float4 o = *reinterpret_cast<const float4*>(d);
+      a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+    }
+    *reinterpret_cast<float4*>(d) = a;
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_scalar_kernel(const float* __restrict__ slabs,
+                                                                  int nslab, int64_t stride,
+                                                                  float* d0, float* d1, float* d2,
+                                                                  int64_t nper, int64_t n,
+                                                                  int accumulate) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    float a = slabs[e];
+    for (int s = 1; s < nslab; ++s) a += slabs[(int64_t)s * stride + e];
+    const int q = (int)(e >= nper) + (int)(e >= 2 * nper);
+    float* d = (q == 0 ? d0 : (q == 1 ? d1 : d2)) + (e - q * nper);
+    *d = accumulate ? *d + a : a;
+  }
+}
+
+// partial[chunk][n] = sum over the chunk's rows of y_seg(n)[m][n % nper]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* y0, const float* y1,
+                                                             const float* y2, int64_t ld,
+                                                             int64_t M, int64_t nper, int64_t N,
+                                                             int64_t rows_per_chunk,
+                                                             float* partial) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int q = (int)(n >= nper) + (int)(n >= 2 * nper);
+  const float* y = (q == 0 ? y0 : (q == 1 ? y1 : y2)) + (n - q * nper);
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+  const int64_t r1 = r0 + rows_per_chunk < M ? r0 + rows_per_chunk : M;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int64_t r = r0;
+  for (; r + 3 < r1; r += 4) {
+    a0 += y[r * ld];
+    a1 += y[(r + 1) * ld];
+    a2 += y[(r + 2) * ld];
+    a3 += y[(r + 3) * ld];
+  }
+  for (; r < r1; ++r) a0 += y[r * ld];
+  partial[(int64_t)blockIdx.y * N + n] = (a0 + a1) + (a2 + a3);
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, float* y,
+                                                  int64_t n) {
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n;
+       i += (int64_t)gridDim.x * blockDim.x * 4) {
+    if (i + 3 < n) {
+      const float4 u = *reinterpret_cast<const float4*>(a + i);
+      const float4 v = *reinterpret_cast<const float4*>(b + i);
+      *reinterpret_cast<float4*>(y + i) = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    } else {
+      for (int64_t j = i; j < n; ++j) y[j] = a[j] + b[j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* src, int64_t src_rpb,
+                                                        int64_t src_off, float* dst,
+                                                        int64_t dst_rpb, int64_t dst_off,
+                                                        int64_t rows, int64_t rpb, int cols,
+                                                        int accumulate) {
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i - r * cols;
+    const int64_t b = r / rpb, l = r - b * rpb;
+    const float v = src[(b * src_rpb + src_off + l) * cols + c];
+    float* d = dst + (b * dst_rpb + dst_off + l) * cols + c;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+// dy[row][col] = keep(row,col) ? dout*scale : 0 ; thread = one column x 4 rows
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* dout, float* dy,
+                                                          int64_t rows, int cols, uint32_t thr,
+                                                          float scale, GctRng rng) {
+  const int64_t ngroups = (rows + 3) / 4;
+  const int64_t total = ngroups * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t gq = i / cols;
+    const int col = (int)(i - gq * cols);
+    const uint4 bits = gct_drop_bits(rng, (uint32_t)gq, (uint32_t)col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t row = gq * 4 + e;
+      if (row < rows) {
+        const int64_t o = row * cols + col;
+        dy[o] = gct_pick(bits, e) >= thr ? dout[o] * scale : 0.f;
+      }
+    }
+  }
+}
+
+inline unsigned grid_for(int64_t work_items, int block = 256, int64_t cap = 4096) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+int gct_reduce_slabs_seg(const float* slabs, int nslab, int64_t stride, float* d0, float* d1,
+                         float* d2, int64_t nper_elems, int64_t n, hipStream_t st) {
+  if (n <= 0) return GCT_OK;
+  const bool vec = (n % 4 == 0) && (nper_elems % 4 == 0) && (stride % 4 == 0) &&
+                   gct_aligned16(slabs) && gct_aligned16(d0) && (!d1 || gct_aligned16(d1)) &&
+                   (!d2 || gct_aligned16(d2));
+  if (vec)
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, slabs, nslab,
+                       stride, d0, d1, d2, nper_elems, n / 4, 0);
+  else
+    hipLaunchKernelGGL(reduce_slabs_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, st, slabs,
+                       nslab, stride, d0, d1, d2, nper_elems, n, 0);
+  GCT_LAUNCH_CHECK("reduce_slabs");
+  return GCT_OK;
+}
+
+static int colsum_chunks(int64_t M) {
+  int64_t c = (M + 127) / 128;
+  if (c > 256) c = 256;
+  if (c < 1) c = 1;
+  return (int)c;
+}
+
+int64_t gct_colsum_ws_floats(int64_t M, int64_t N) { return (int64_t)colsum_chunks(M) * N; }
+
+int gct_colsum(const float* y0, const float* y1, const float* y2, int64_t ld, int64_t M, int nseg,
+               int nper, float* d0, float* d1, float* d2, float* ws, hipStream_t st) {
+  const int64_t N = (int64_t)nseg * nper;
+  const int chunks = colsum_chunks(M);
+  const int64_t rpc = (M + chunks - 1) / chunks;
+  dim3 grid((unsigned)((N + 255) / 256), (unsigned)chunks);
+  hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, st, y0, y1, y2, ld, M,
+                     (int64_t)nper, N, rpc > 0 ? rpc : 1, ws);
+  GCT_LAUNCH_CHECK("colsum_partial");
+  return gct_reduce_slabs_seg(ws, chunks, N, d0, d1, d2, nper, N, st);
+}
+
+extern "C" int64_t gct_rowred_ws_bytes(int64_t rows, int64_t cols) {
+  return (gct_colsum_ws_floats(rows, cols) + 1024 * cols) * (int64_t)sizeof(float) + 256;
+}
+
+extern "C" int gct_reduce_slabs(const float* slabs, int nslab, int64_t stride, float* dst,
+                                int64_t n, int accumulate, void* stream) {
+  GCT_CHECK_ARG(slabs && dst && nslab >= 1 && n >= 0, "reduce_slabs: bad args");
+  if (n == 0) return GCT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t big = INT64_MAX / 4;
+  const bool vec = (n % 4 == 0) && (stride % 4 == 0) && gct_aligned16(slabs) && gct_aligned16(dst);
+  if (vec)
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, slabs, nslab,
+                       stride, dst, dst, dst, big, n / 4, accumulate);
+  else
+    hipLaunchKernelGGL(reduce_slabs_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, st, slabs,
+                       nslab, stride, dst, dst, dst, big, n, accumulate);
+  GCT_LAUNCH_CHECK("reduce_slabs");
+  return GCT_OK;
+}
+
+extern "C" int gct_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
+  GCT_CHECK_ARG(a && b && y && n >= 0, "add: bad args");
+  if (n == 0) return GCT_OK;
+  GCT_CHECK_ARG(gct_aligned16(a) && gct_aligned16(b) && gct_aligned16(y), "add: unaligned");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a,
+                     b, y, n);
+  GCT_LAUNCH_CHECK("add");
+  return GCT_OK;
+}
+
+extern "C" int gct_copy_rows(const float* src, int64_t src_rpb, int64_t src_off, float* dst,
+                             int64_t dst_rpb, int64_t dst_off, int64_t rows, int64_t rpb, int cols,
+                             int accumulate, void* stream) {
+  GCT_CHECK_ARG(src && dst && rows >= 0 && rpb > 0 && cols > 0, "copy_rows: bad args");
+  if (rows == 0) return GCT_OK;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(rows * cols)), dim3(256), 0,
+                     (hipStream_t)stream, src, src_rpb, src_off, dst, dst_rpb, dst_off, rows, rpb,
+                     cols, accumulate);
+  GCT_LAUNCH_CHECK("copy_rows");
+  return GCT_OK;
+}
+
+extern "C" int gct_dropout_bwd(const float* dout, float* dy, int64_t rows, int cols, float p,
+                               uint64_t seed, uint32_t site, void* stream) {
+  GCT_CHECK_ARG(dout && dy && rows >= 0 && cols > 0 && p >= 0.f && p < 1.f, "dropout_bwd: bad args");
+  if (rows == 0) return GCT_OK;
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(((rows + 3) / 4) * cols)), dim3(256), 0,
+                     (hipStream_t)stream, dout, dy, rows, cols, gct_drop_threshold(p),
+                     1.0f / (1.0f - p), gct_rng_make(seed, site));
+  GCT_LAUNCH_CHECK("dropout_bwd");
+  return GCT_OK;
+}

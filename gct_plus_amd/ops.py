@@ -1,0 +1,275 @@
+"""Thin, allocation-explicit Python wrappers over the C ABI (include/gctplus_hip.h).
+
+Every function takes/returns fp32 CUDA tensors, enqueues on the current torch stream and
+never synchronises.  No autograd here: `engine.py` composes these into hand-written
+forward/backward passes.  PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+EPI_BIAS, EPI_GELU_DROP, EPI_DROP_RESID = 0, 1, 2
+DEPI_STORE, DEPI_ACCUM, DEPI_GELU_BWD = 0, 1, 2
+
+
+def _L():
+    return _lib.load()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not t.is_cuda:
+        raise _lib.GctError(f"{name}: expected a CUDA (ROCm) tensor; gct_plus_amd has no CPU path")
+    if t.dtype != dtype:
+        raise _lib.GctError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+# ------------------------------------------------------------------------------ workspace
+_WS = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Per (device, stream) scratch buffer, grown geometrically; kernels on one stream are
+    ordered, so consecutive ops may reuse it."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _st())
+    buf = _WS.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        n = max(int(nbytes * 1.25) // 4 + 64, 1 << 20)
+        buf = torch.empty(n, dtype=torch.float32, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# ----------------------------------------------------------------------------------- norm
+def norm_fwd(x2d, alpha, bias, eps=1e-6, out=None):
+    _chk(x2d, "norm_fwd.x")
+    rows, d = x2d.shape
+    y = torch.empty_like(x2d) if out is None else out
+    mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    check(_L().gct_norm_fwd(_p(x2d), _p(alpha), _p(bias), _p(y), _p(mean), _p(rstd), rows, d, eps,
+                            _st()), "gct_norm_fwd")
+    return y, mean, rstd
+
+
+def norm_bwd(dy, x2d, alpha, mean, rstd, dalpha, dbias, dres=None, out=None, eps=1e-6):
+    rows, d = x2d.shape
+    dx = torch.empty_like(x2d) if out is None else out
+    ws = workspace(_L().gct_rowred_ws_bytes(rows, 2 * d), x2d.device)
+    check(_L().gct_norm_bwd(_p(dy), _p(x2d), _p(alpha), _p(mean), _p(rstd), _p(dres), _p(dx),
+                            _p(dalpha), _p(dbias), _p(ws), rows, d, eps, _st()), "gct_norm_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------ embedding
+def embed_pe_fwd(tok, table, cond, pe2d, n_c, scale, p, seed, site):
+    _chk(tok, "embed.tok", torch.int64)
+    B, S = tok.shape
+    vocab, d = table.shape
+    out = torch.empty(B * (S + n_c), d, dtype=torch.float32, device=table.device)
+    check(_L().gct_embed_pe_fwd(_p(tok), _p(table), _p(cond), _p(pe2d), _p(out), B, S, n_c, d, vocab,
+                                scale, p, seed, site, _st()), "gct_embed_pe_fwd")
+    return out
+
+
+def embed_pe_bwd(dout, tok, dtable, dcond, n_c, scale, p, seed, site):
+    B, S = tok.shape
+    vocab, d = dtable.shape
+    ws = workspace(_L().gct_embed_ws_bytes(B, S, d, vocab), dout.device)
+    check(_L().gct_embed_pe_bwd(_p(dout), _p(tok), _p(dtable), _p(dcond), _p(ws), B, S, n_c, d, vocab,
+                                scale, p, seed, site, _st()), "gct_embed_pe_bwd")
+
+
+# --------------------------------------------------------------------------------- linear
+def _seg3(ts: Sequence[Optional[torch.Tensor]]):
+    ts = list(ts) + [None] * (3 - len(ts))
+    return [_p(t) for t in ts]
+
+
+def linear_fwd(x2d, ws_: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Tensor]],
+               outs: Sequence[torch.Tensor], ldy: int, epi=EPI_BIAS, resid=None, pre=None,
+               p=0.0, seed=0, site=0):
+    """y_s = epi(x @ w_s^T + b_s); outs are (views of) pre-allocated [M, nper] blocks with
+    leading dimension ldy."""
+    M, K = x2d.shape
+    nper = ws_[0].shape[0]
+    w = _seg3(ws_)
+    b = _seg3(bs)
+    y = _seg3(outs)
+    check(_L().gct_linear_fwd(_p(x2d), x2d.stride(0), M, K, w[0], w[1], w[2], ws_[0].stride(0),
+                              b[0], b[1], b[2], len(ws_), nper, y[0], y[1], y[2], ldy, epi,
+                              _p(resid), _p(pre), p, seed, site, _st()), "gct_linear_fwd")
+
+
+def linear_dgrad(dys: Sequence[torch.Tensor], lddy: int, M: int, ws_: Sequence[torch.Tensor], dx,
+                 depi=DEPI_STORE, pre=None, p=0.0, seed=0, site=0):
+    nper, K = ws_[0].shape
+    d = _seg3(dys)
+    w = _seg3(ws_)
+    check(_L().gct_linear_dgrad(d[0], d[1], d[2], lddy, M, len(ws_), nper, w[0], w[1], w[2],
+                                ws_[0].stride(0), K, _p(dx), dx.stride(0), depi, _p(pre), p, seed,
+                                site, _st()), "gct_linear_dgrad")
+
+
+def linear_wgrad(dys: Sequence[torch.Tensor], lddy: int, x2d, dws: Sequence[torch.Tensor],
+                 dbs: Sequence[Optional[torch.Tensor]]):
+    M, K = x2d.shape
+    nper = dws[0].shape[0]
+    nseg = len(dws)
+    d = _seg3(dys)
+    dw = _seg3(dws)
+    db = _seg3(dbs)
+    ws = workspace(_L().gct_wgrad_ws_bytes(M, nseg * nper, K), x2d.device)
+    check(_L().gct_linear_wgrad(d[0], d[1], d[2], lddy, M, nseg, nper, _p(x2d), x2d.stride(0), K,
+                                dw[0], dw[1], dw[2], K, db[0], db[1], db[2], _p(ws), _st()),
+          "gct_linear_wgrad")
+
+
+def dropout_bwd(dout2d, p, seed, site, out=None):
+    rows, cols = dout2d.shape
+    dy = torch.empty_like(dout2d) if out is None else out
+    check(_L().gct_dropout_bwd(_p(dout2d), _p(dy), rows, cols, p, seed, site, _st()),
+          "gct_dropout_bwd")
+    return dy
+
+
+# ------------------------------------------------------------------------------ attention
+def attn_fwd(q, k, v, ld_q, ld_k, ld_v, mask_u8, B, H, Lq, Lk, dk, p, seed, site, out=None,
+             want_probs=False):
+    """q/k/v: tensors whose data_ptr is element (b=0,l=0,h=0,0) with row strides ld_*.
+    mask_u8: None | [B,Lk] / [B,1,Lk] (key padding) | [B,Lq,Lk]."""
+    dev = q.device
+    o = torch.empty(B * Lq, H * dk, dtype=torch.float32, device=dev) if out is None else out
+    lse = torch.empty(B * H * Lq, dtype=torch.float32, device=dev)
+    probs = torch.empty(B, H, Lq, Lk, dtype=torch.float32, device=dev) if want_probs else None
+    sb, sq = _mask_strides(mask_u8, B, Lq, Lk)
+    check(_L().gct_attn_fwd(_p(q), ld_q, _p(k), ld_k, _p(v), ld_v, _p(mask_u8), sb, sq, _p(o),
+                            o.stride(0), _p(lse), _p(probs), B, H, Lq, Lk, dk,
+                            1.0 / math.sqrt(dk), p, seed, site, _st()), "gct_attn_fwd")
+    return o, lse, probs
+
+
+def attn_bwd(q, k, v, ld_q, ld_k, ld_v, mask_u8, o, dout, lse, dq, dk_, dv, ld_dq, ld_dk, ld_dv,
+             B, H, Lq, Lk, dk, p, seed, site):
+    sb, sq = _mask_strides(mask_u8, B, Lq, Lk)
+    check(_L().gct_attn_bwd(_p(q), ld_q, _p(k), ld_k, _p(v), ld_v, _p(mask_u8), sb, sq, _p(o),
+                            _p(dout), o.stride(0), _p(lse), None, _p(dq), ld_dq, _p(dk_), ld_dk,
+                            _p(dv), ld_dv, B, H, Lq, Lk, dk, 1.0 / math.sqrt(dk), p, seed, site,
+                            _st()), "gct_attn_bwd")
+
+
+def _mask_strides(mask_u8, B, Lq, Lk):
+    if mask_u8 is None:
+        return 0, 0
+    _chk(mask_u8, "attn.mask", torch.uint8)
+    n = mask_u8.numel()
+    if n == B * Lk:
+        return Lk, 0
+    if n == B * Lq * Lk:
+        return Lq * Lk, Lk
+    raise _lib.GctError(f"attention mask with {n} elements fits neither [B,Lk] nor [B,Lq,Lk] "
+                        f"(B={B}, Lq={Lq}, Lk={Lk})")
+
+
+def to_mask_u8(mask: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """Reference masks are bool [B,1,Lk] (Model/modules.py:38-44) or int64 [B,T,T]
+    (modules.py:47-58); the kernels take uint8 (0 = masked)."""
+    if mask is None:
+        return None
+    if mask.dtype == torch.uint8:
+        return mask.contiguous()
+    return (mask != 0).to(torch.uint8).contiguous()
+
+
+# -------------------------------------------------------------------------------- VAE / loss
+def reparam_fwd(mu, log_var, eps, seed, site):
+    z = torch.empty_like(mu)
+    eps_out = torch.empty_like(mu)
+    check(_L().gct_reparam_fwd(_p(mu), _p(log_var), _p(eps), _p(eps_out), _p(z), mu.numel(), seed,
+                               site, _st()), "gct_reparam_fwd")
+    return z, eps_out
+
+
+def reparam_bwd(dz, log_var, eps, dmu_ext, dlv_ext, dmu, dlv):
+    check(_L().gct_reparam_bwd(_p(dz), _p(log_var), _p(eps), _p(dmu_ext), _p(dlv_ext), _p(dmu),
+                               _p(dlv), dz.numel(), _st()), "gct_reparam_bwd")
+
+
+def kld_fwd(mu, log_var):
+    out = torch.empty((), dtype=torch.float32, device=mu.device)
+    ws = workspace(4096, mu.device)
+    check(_L().gct_kld_fwd(_p(mu), _p(log_var), _p(out), _p(ws), mu.numel(), _st()), "gct_kld_fwd")
+    return out
+
+
+def kld_bwd(mu, log_var, gout):
+    dmu, dlv = torch.empty_like(mu), torch.empty_like(log_var)
+    check(_L().gct_kld_bwd(_p(mu), _p(log_var), _p(gout), _p(dmu), _p(dlv), mu.numel(), _st()),
+          "gct_kld_bwd")
+    return dmu, dlv
+
+
+def ce_fwd(logits2d, target, pad_id):
+    _chk(target, "ce.target", torch.int64)
+    rows, V = logits2d.shape
+    out = torch.empty((), dtype=torch.float32, device=logits2d.device)
+    ws = workspace(4096, logits2d.device)
+    check(_L().gct_ce_fwd(_p(logits2d), _p(target), _p(out), _p(ws), rows, V, pad_id, _st()),
+          "gct_ce_fwd")
+    return out
+
+
+def ce_bwd(logits2d, target, gout, pad_id):
+    rows, V = logits2d.shape
+    dl = torch.empty_like(logits2d)
+    check(_L().gct_ce_bwd(_p(logits2d), _p(target), _p(gout), _p(dl), rows, V, pad_id, _st()),
+          "gct_ce_bwd")
+    return dl
+
+
+# ------------------------------------------------------------------------------- optimiser
+def adam_step(p, g, m, v, lr, b1, b2, eps, step, gscale=1.0):
+    check(_L().gct_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, step, gscale,
+                             _st()), "gct_adam_step")
+
+
+# ---------------------------------------------------------------------------------- utility
+def copy_rows(src, src_rpb, src_off, dst, dst_rpb, dst_off, rows, rpb, cols, accumulate=False):
+    check(_L().gct_copy_rows(_p(src), src_rpb, src_off, _p(dst), dst_rpb, dst_off, rows, rpb, cols,
+                             int(accumulate), _st()), "gct_copy_rows")
+
+
+def small_linear_fwd(x, w, b):
+    rows, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(rows, N, dtype=torch.float32, device=x.device)
+    check(_L().gct_small_linear_fwd(_p(x), _p(w), _p(b), _p(y), rows, K, N, _st()),
+          "gct_small_linear_fwd")
+    return y
+
+
+def small_linear_bwd(dy, x, dw, db):
+    rows, K = x.shape
+    N = dw.shape[0]
+    check(_L().gct_small_linear_bwd(_p(dy), _p(x), _p(dw), _p(db), rows, K, N, _st()),
+          "gct_small_linear_bwd")
+
+
+def add(a, b, out=None):
+    y = torch.empty_like(a) if out is None else out
+    check(_L().gct_add(_p(a), _p(b), _p(y), a.numel(), _st()), "gct_add")
+    return y

@@ -1,0 +1,196 @@
+/*
+ * gctplus_hip.h -- C ABI of libgctplus_hip.so (gfx950 / MI355X).
+ *
+ * The reference (chaoting-sun/GCT-Plus) is pure Python/PyTorch and has NO plugin,
+ * operator or FFI interface; the drop-in boundary is the Python
+ * nn.Module contract (Model/build_model.py:79-87 get_model, Vaetf/Cvaetf.forward
+ * Model/vaetf.py:154-182, Model/cvaetf.py:179-193).  This header is the ABI the
+ * build adds UNDERNEATH that contract: one entry point per ATen call site group of
+ * SURVEY.md 2.2 (K1..K10).  Each declaration cites the reference call site whose
+ * arithmetic it replaces.
+ *
+ * Conventions
+ *  - plain C: raw device pointers, sizes, scalars, a hipStream_t passed as void*.
+ *  - all tensors fp32 row-major unless stated; token ids int64; masks uint8.
+ *  - the caller owns every buffer (PyTorch caching allocator); the library allocates
+ *    nothing and never synchronises; kernels are enqueued on `stream`.
+ *  - return 0 on success, <0 on error (GCT_ERR_*); message via gct_last_error()
+ *    (thread-local).  Never throws, never exits.
+ *  - "segmented" matrices: a logical [R][nseg*nper] matrix whose column block s
+ *    (or row block s for weights) lives behind its own pointer p[s].  This is how the
+ *    separate q/k/v (and mu/log_var) nn.Linear parameters of the reference are fused
+ *    into one GEMM without repacking or renaming any checkpoint tensor.
+ *  - dropout: Philox4x32-10, key = (seed, site), counter = element coordinates; the
+ *    backward kernels regenerate the mask from (seed, site), nothing is stored.
+ *    p == 0 disables it (bit-exact parity mode, SURVEY.md 7 "RNG").
+ */
+#ifndef GCTPLUS_HIP_H
+#define GCTPLUS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCT_OK 0
+#define GCT_ERR_ARG (-1)  /* bad shape / alignment / null pointer            */
+#define GCT_ERR_HIP (-2)  /* a HIP runtime call failed (launch error)        */
+
+#define GCT_ABI_VERSION 1
+
+int gct_version(void);
+const char* gct_last_error(void);
+
+/* workspace sizing helpers (bytes); the caller allocates */
+int64_t gct_wgrad_ws_bytes(int64_t M, int64_t Ntot, int64_t K);
+int64_t gct_rowred_ws_bytes(int64_t rows, int64_t cols);
+
+/* ------------------------------------------------------------------ K2: Norm */
+/* Model/modules.py:92-95   y = alpha*(x-mean)/(std_unbiased+eps)+bias.
+ * Saves mean[rows] and rstd[rows] = 1/(std+eps) for the backward. d % 4 == 0, d <= 2048. */
+int gct_norm_fwd(const float* x, const float* alpha, const float* bias, float* y,
+                 float* mean, float* rstd, int64_t rows, int d, float eps, void* stream);
+/* dx = dNorm/dx (dy) [+ dres]; dalpha, dbias overwritten. ws >= gct_rowred_ws_bytes(rows, 2*d). */
+int gct_norm_bwd(const float* dy, const float* x, const float* alpha, const float* mean,
+                 const float* rstd, const float* dres, float* dx, float* dalpha, float* dbias,
+                 float* ws, int64_t rows, int d, float eps, void* stream);
+
+/* --------------------------------------------------- K1: embedding + PE (+cond) */
+/* Model/modules.py:108-110 (lookup), :134-144 (x*sqrt(d)+pe, dropout),
+ * Model/vaetf.py:35-39 (cond rows concatenated in front).  out row (b,l):
+ *   l <  n_c : cond[b][l][:]        (cond = embed_cond2enc(econds) viewed [B,n_c,d])
+ *   l >= n_c : table[tok[b][l-n_c]][:]
+ * then *scale + pe[l][:], dropout(site).  L = n_c + S. */
+int gct_embed_pe_fwd(const int64_t* tok, const float* table, const float* cond, const float* pe,
+                     float* out, int B, int S, int n_c, int d, int vocab, float scale, float p,
+                     uint64_t seed, uint32_t site, void* stream);
+/* dtable[vocab][d] overwritten (deterministic two-stage reduction), dcond[B][n_c][d]
+ * overwritten (nullable when n_c == 0). ws >= gct_embed_ws_bytes. */
+int64_t gct_embed_ws_bytes(int B, int S, int d, int vocab);
+int gct_embed_pe_bwd(const float* dout, const int64_t* tok, float* dtable, float* dcond,
+                     float* ws, int B, int S, int n_c, int d, int vocab, float scale, float p,
+                     uint64_t seed, uint32_t site, void* stream);
+
+/* ------------------------------------------------------------- K3: nn.Linear */
+/* Model/sublayers.py:54-59,64-66,70 (q/k/v/out), :81-88 (FFN), :11-12 (fc_mu,
+ * fc_log_var), Model/vaetf.py:81 (fc_z), :133/:169 (out).  fp32-input MFMA
+ * (v_mfma_f32_32x32x2_f32): results are exact-fp32 fma chains.
+ *
+ * y_s[m][n] = epi( sum_k x[m][k] * w_s[n][k] + b_s[n] )   s = 0..nseg-1, n < nper
+ *   GCT_EPI_BIAS       : plain
+ *   GCT_EPI_GELU_DROP  : pre[m][n] = acc+b (saved), y = dropout(gelu_erf(pre))   (FFN-1)
+ *   GCT_EPI_DROP_RESID : y = resid[m][n] + dropout(acc+b)                         (out / FFN-2)
+ * pre/resid share y's leading dimension and are only valid with nseg == 1. */
+#define GCT_EPI_BIAS 0
+#define GCT_EPI_GELU_DROP 1
+#define GCT_EPI_DROP_RESID 2
+int gct_linear_fwd(const float* x, int64_t ldx, int64_t M, int K,
+                   const float* w0, const float* w1, const float* w2, int64_t ldw,
+                   const float* b0, const float* b1, const float* b2, int nseg, int nper,
+                   float* y0, float* y1, float* y2, int64_t ldy,
+                   int epi, const float* resid, float* pre, float p, uint64_t seed, uint32_t site,
+                   void* stream);
+
+/* dx[m][k] (op)= sum_s sum_n dy_s[m][n] * w_s[n][k]
+ *   GCT_DEPI_STORE / GCT_DEPI_ACCUM (dx += ...) /
+ *   GCT_DEPI_GELU_BWD : dx = acc * gelu'(pre[m][k]) * dropmask(site)/(1-p)   (through FFN-1 act.) */
+#define GCT_DEPI_STORE 0
+#define GCT_DEPI_ACCUM 1
+#define GCT_DEPI_GELU_BWD 2
+int gct_linear_dgrad(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
+                     int64_t M, int nseg, int nper,
+                     const float* w0, const float* w1, const float* w2, int64_t ldw, int K,
+                     float* dx, int64_t lddx, int depi, const float* pre, float p, uint64_t seed,
+                     uint32_t site, void* stream);
+
+/* dw_s[n][k] = sum_m dy_s[m][n] * x[m][k] ; db_s[n] = sum_m dy_s[m][n]  (overwrite).
+ * Split over M into fp32 slabs in ws, reduced deterministically (no atomics).
+ * ws >= gct_wgrad_ws_bytes(M, nseg*nper, K). db* nullable. */
+int gct_linear_wgrad(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
+                     int64_t M, int nseg, int nper, const float* x, int64_t ldx, int K,
+                     float* dw0, float* dw1, float* dw2, int64_t lddw,
+                     float* db0, float* db1, float* db2, float* ws, void* stream);
+
+/* elementwise dropout backward for the GCT_EPI_DROP_RESID sites: dy = dropmask*dout/(1-p) */
+int gct_dropout_bwd(const float* dout, float* dy, int64_t rows, int cols, float p, uint64_t seed,
+                    uint32_t site, void* stream);
+
+/* ------------------------------------------------------------- K4: attention */
+/* Model/sublayers.py:29-41 attention() + head split/merge :64-69.
+ * q,k,v are [B][L][H*dk]-shaped views with leading dimension ld* (so the fused QKV
+ * buffer is consumed in place); head h uses columns h*dk..h*dk+dk-1.
+ * mask: uint8, element (b,q,k) at mask[b*mask_sb + q*mask_sq + k]; 0 => score := -1e9
+ * (masked_fill semantics; mask_sq == 0 broadcasts a key-padding mask). nullable.
+ * o: [B][Lq][H*dk] (heads merged, ready for the out projection); lse: [B][H][Lq].
+ * probs (nullable): pre-dropout probabilities [B][H][Lq][Lk] (get_attn path).
+ * dk % 4 == 0, dk <= 64, Lq,Lk <= 128. */
+int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                 int64_t ldv, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
+                 float* o, int64_t ldo, float* lse, float* probs, int B, int H, int Lq, int Lk,
+                 int dk, float scale, float p, uint64_t seed, uint32_t site, void* stream);
+/* dq/dk/dv written (overwrite) with the same layout as q/k/v. delta: scratch [B][H][Lq]. */
+int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                 int64_t ldv, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
+                 const float* o, const float* dout, int64_t ldo, const float* lse, float* delta,
+                 float* dq, int64_t lddq, float* dk_, int64_t lddk, float* dv, int64_t lddv,
+                 int B, int H, int Lq, int Lk, int dk, float scale, float p, uint64_t seed,
+                 uint32_t site, void* stream);
+
+/* ------------------------------------------------- K6: reparameterisation + KL */
+/* Model/sublayers.py:14-20 / Model/cvaetf.py:63-69: z = eps*exp(0.5*log_var)+mu.
+ * eps_in nullable: then eps ~ N(0,1) is generated in-kernel (Philox + Box-Muller,
+ * key (seed,site)) and written to eps_out (always written). */
+int gct_reparam_fwd(const float* mu, const float* log_var, const float* eps_in, float* eps_out,
+                    float* z, int64_t n, uint64_t seed, uint32_t site, void* stream);
+/* dmu = dz + dmu_ext ; dlv = 0.5*dz*eps*exp(0.5*lv) + dlv_ext  (ext nullable) */
+int gct_reparam_bwd(const float* dz, const float* log_var, const float* eps, const float* dmu_ext,
+                    const float* dlv_ext, float* dmu, float* dlv, int64_t n, void* stream);
+/* Train/trainer1.py:23  KLD = -0.5*sum(1+lv-mu^2-exp(lv)) over ALL n elements.
+ * out[0] overwritten. ws >= 1024 floats. */
+int gct_kld_fwd(const float* mu, const float* log_var, float* out, float* ws, int64_t n,
+                void* stream);
+/* dmu = g*mu ; dlv = g*0.5*(exp(lv)-1), g read from device scalar gout[0] */
+int gct_kld_bwd(const float* mu, const float* log_var, const float* gout, float* dmu, float* dlv,
+                int64_t n, void* stream);
+
+/* ---------------------------------------------------------- K7: cross-entropy */
+/* Train/trainer1.py:21-22  F.cross_entropy(logits.view(-1,V), ys, ignore_index=pad,
+ * reduction='sum').  out[0] overwritten. ws >= 1024 floats. */
+int gct_ce_fwd(const float* logits, const int64_t* target, float* out, float* ws, int64_t rows,
+               int V, int64_t pad_id, void* stream);
+/* dlogits = g*(softmax - onehot) on non-pad rows, 0 on pad rows; g = gout[0] (device). */
+int gct_ce_bwd(const float* logits, const int64_t* target, const float* gout, float* dlogits,
+               int64_t rows, int V, int64_t pad_id, void* stream);
+
+/* -------------------------------------------------------------- K8: Adam step */
+/* torch.optim.Adam semantics (train1.py:116-119; no weight decay, no amsgrad):
+ *   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
+ *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * over one flat buffer of n elements; g is multiplied by gscale first (1/W folds the
+ * data-parallel mean). `step` is t (1-based, already incremented). */
+int gct_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                  float b2, float eps, int64_t step, float gscale, void* stream);
+
+/* ------------------------------------------------------------------ utilities */
+/* dst[(r / rpb)*dst_rpb + dst_off + r % rpb][:] (op)= src[(r / rpb)*src_rpb + src_off + r % rpb][:]
+ * row gather/scatter used for the cond2lat concat (Model/vaetf.py:88-91). accumulate: += */
+int gct_copy_rows(const float* src, int64_t src_rpb, int64_t src_off, float* dst, int64_t dst_rpb,
+                  int64_t dst_off, int64_t rows, int64_t rpb, int cols, int accumulate,
+                  void* stream);
+/* tiny dense layer for the property embeddings (Model/vaetf.py:30,75-77; K = n_c <= 8):
+ * y[b][n] = sum_k x[b][k]*w[n][k] + b[n]; bwd gives dw, db (overwrite) and no dx. */
+int gct_small_linear_fwd(const float* x, const float* w, const float* b, float* y, int rows,
+                         int K, int N, void* stream);
+int gct_small_linear_bwd(const float* dy, const float* x, float* dw, float* db, int rows, int K,
+                         int N, void* stream);
+/* dst[i] = sum_s slabs[s*stride + i] (deterministic slab reduction) */
+int gct_reduce_slabs(const float* slabs, int nslab, int64_t stride, float* dst, int64_t n,
+                     int accumulate, void* stream);
+/* y = a + b (gradient joins of the residual stream) */
+int gct_add(const float* a, const float* b, float* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCTPLUS_HIP_H */

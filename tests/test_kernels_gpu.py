@@ -1,0 +1,346 @@
+"""Per-kernel parity: every C-ABI entry point (through gct_plus_amd.ops) against an fp64
+PyTorch-CPU restatement of the same op.  Tolerances are stated per test; fp32 MFMA is an
+exact-fp32 fma chain so 1e-5-level agreement with fp64 is expected at these sizes."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from gct_plus_amd import ops as _ops
+    _ops._L()
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def close(got, ref, atol, rtol, what=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    assert not bad.any(), f"{what}: max err {err.max().item():.3e} (ref scale {ref.abs().max().item():.3e}), {int(bad.sum())} bad"
+
+
+def ref_norm(x, a, b, eps=1e-6):
+    return a * (x - x.mean(-1, keepdim=True)) / (x.std(-1, keepdim=True) + eps) + b
+
+
+@pytest.mark.parametrize("rows,d", [(7, 64), (1000, 512), (33, 2048), (5, 12)])
+def test_norm(ops, rows, d):
+    x, a, b, dy, dres = rnd(rows, d, seed=1), rnd(d, seed=2) + 1, rnd(d, seed=3), rnd(rows, d, seed=4), rnd(rows, d, seed=5)
+    y, mean, rstd = ops.norm_fwd(x.to(DEV), a.to(DEV), b.to(DEV))
+    xd, ad, bd = x.double().requires_grad_(), a.double().requires_grad_(), b.double().requires_grad_()
+    yr = ref_norm(xd, ad, bd)
+    close(y, yr, 1e-5, 1e-5, "norm fwd")
+    yr.backward(dy.double())
+    da, db = torch.empty(d, device=DEV), torch.empty(d, device=DEV)
+    dx = ops.norm_bwd(dy.to(DEV), x.to(DEV), a.to(DEV), mean, rstd, da, db, dres=dres.to(DEV))
+    close(dx, xd.grad + dres.double(), 2e-5, 1e-4, "norm dx")
+    close(da, ad.grad, 1e-4 * math.sqrt(rows), 1e-4, "norm dalpha")
+    close(db, bd.grad, 1e-4 * math.sqrt(rows), 1e-4, "norm dbias")
+
+
+def test_norm_known_answer(ops):
+    # Norm(4)([1,2,3,4])
+    y, _, _ = ops.norm_fwd(torch.tensor([[1.0, 2.0, 3.0, 4.0]], device=DEV), torch.ones(4, device=DEV), torch.zeros(4, device=DEV))
+    close(y, torch.tensor([[-1.161894, -0.387298, 0.387298, 1.161894]]), 1e-6, 0, "norm known answer")
+
+
+@pytest.mark.parametrize("M,K,nper,nseg", [(300, 512, 512, 3), (129, 64, 64, 3), (5184, 512, 30, 1),
+                                           (260, 128, 512, 1), (1000, 2048, 512, 1), (77, 512, 128, 2)])
+def test_linear_fwd_dgrad_wgrad(ops, M, K, nper, nseg):
+    x = rnd(M, K, seed=1)
+    ws = [rnd(nper, K, seed=10 + s, scale=K ** -0.5) for s in range(nseg)]
+    bs = [rnd(nper, seed=20 + s) for s in range(nseg)]
+    N = nper * nseg
+    y = torch.empty(M, N, device=DEV)
+    outs = [y[:, s * nper:] for s in range(nseg)]
+    xg = x.to(DEV)
+    wg = [w.to(DEV) for w in ws]
+    bg = [b.to(DEV) for b in bs]
+    ops.linear_fwd(xg, wg, bg, outs, N)
+    W = torch.cat(ws).double()
+    ref = x.double() @ W.t() + torch.cat(bs).double()
+    close(y, ref, 2e-5, 2e-5, "linear fwd")
+    # dgrad
+    dy = rnd(M, N, seed=3)
+    dyg = dy.to(DEV)
+    dys = [dyg[:, s * nper:] for s in range(nseg)]
+    dx = torch.empty(M, K, device=DEV)
+    ops.linear_dgrad(dys, N, M, wg, dx)
+    close(dx, dy.double() @ W, 5e-5, 5e-5, "linear dgrad")
+    base = rnd(M, K, seed=4)
+    dx2 = base.to(DEV).clone()
+    ops.linear_dgrad(dys, N, M, wg, dx2, depi=ops.DEPI_ACCUM)
+    close(dx2, dy.double() @ W + base.double(), 5e-5, 5e-5, "linear dgrad accum")
+    # wgrad
+    dws = [torch.empty(nper, K, device=DEV) for _ in range(nseg)]
+    dbs = [torch.empty(nper, device=DEV) for _ in range(nseg)]
+    ops.linear_wgrad(dys, N, xg, dws, dbs)
+    refw = dy.double().t() @ x.double()
+    close(torch.cat(dws), refw, 1e-4 * math.sqrt(M / 100 + 1), 1e-4, "linear wgrad")
+    close(torch.cat(dbs), dy.double().sum(0), 1e-4 * math.sqrt(M / 100 + 1), 1e-4, "linear bias grad")
+
+
+def test_linear_epilogues_no_dropout(ops):
+    M, K, N = 200, 64, 256
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3), rnd(M, N, seed=4)
+    xg, wg, bg, rg = x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
+    y = torch.empty(M, N, device=DEV)
+    pre = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(xg, [wg], [bg], [y], N, epi=ops.EPI_GELU_DROP, pre=pre)
+    u = x.double() @ w.double().t() + b.double()
+    close(pre, u, 2e-5, 2e-5, "pre")
+    close(y, F.gelu(u), 2e-5, 2e-5, "gelu")
+    ops.linear_fwd(xg, [wg], [bg], [y], N, epi=ops.EPI_DROP_RESID, resid=rg)
+    close(y, u + r.double(), 2e-5, 2e-5, "resid")
+    # GELU backward epilogue: dx = (dy @ W2) * gelu'(pre)
+    W2 = rnd(K, N, seed=5, scale=0.1)
+    dy = rnd(M, K, seed=6)
+    dpre = torch.empty(M, N, device=DEV)
+    ops.linear_dgrad([dy.to(DEV)], K, M, [W2.to(DEV)], dpre, depi=ops.DEPI_GELU_BWD, pre=pre)
+    ud = u.clone().requires_grad_()
+    (F.gelu(ud) * (dy.double() @ W2.double())).sum().backward()
+    close(dpre, ud.grad, 2e-5, 1e-4, "gelu bwd")
+
+
+def test_dropout_sites_consistent(ops):
+    """fwd epilogue masks == masks regenerated by the backward kernels; keep rate ~ 1-p."""
+    M, K, N, p, seed = 512, 64, 256, 0.1, 1234
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3)
+    xg, wg, bg = x.to(DEV), w.to(DEV), b.to(DEV)
+    zeros = torch.zeros(M, N, device=DEV)
+    y = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(xg, [wg], [bg], [y], N, epi=ops.EPI_DROP_RESID, resid=zeros, p=p, seed=seed, site=7)
+    u = (x.double() @ w.double().t() + b.double())
+    keep = (y != 0).cpu()
+    rate = keep.float().mean().item()
+    assert abs(rate - (1 - p)) < 0.01, rate
+    close(y, torch.where(keep, u / (1 - p), torch.zeros_like(u)), 3e-5, 3e-5, "dropout fwd values")
+    ones = torch.ones(M, N, device=DEV)
+    dmask = ops.dropout_bwd(ones, p, seed, 7)
+    assert torch.equal((dmask != 0).cpu(), keep)
+    close(dmask, keep.double() / (1 - p), 1e-6, 1e-6)
+    other = ops.dropout_bwd(ones, p, seed, 8)
+    assert not torch.equal((other != 0).cpu(), keep)          # different site => different mask
+    # GELU_DROP site vs GELU_BWD site
+    pre = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(xg, [wg], [bg], [y], N, epi=ops.EPI_GELU_DROP, pre=pre, p=p, seed=seed, site=9)
+    keep2 = (y != 0).cpu() | (F.gelu(u) == 0)
+    dy = rnd(M, K, seed=6)
+    W2 = rnd(K, N, seed=5, scale=0.1)
+    dpre = torch.empty(M, N, device=DEV)
+    ops.linear_dgrad([dy.to(DEV)], K, M, [W2.to(DEV)], dpre, depi=ops.DEPI_GELU_BWD, pre=pre, p=p, seed=seed, site=9)
+    ud = u.clone().requires_grad_()
+    (F.gelu(ud) * keep2.double() / (1 - p) * (dy.double() @ W2.double())).sum().backward()
+    close(dpre, ud.grad, 3e-5, 1e-4, "gelu+dropout bwd")
+
+
+def ref_attention(q, k, v, mask, scale, keep=None, pkeep=1.0):
+    s = q @ k.transpose(-1, -2) * scale
+    if mask is not None:
+        s = s.masked_fill(mask == 0, -1e9)
+    pr = s.softmax(-1)
+    pd = pr if keep is None else pr * keep / pkeep
+    return pd @ v, pr
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,dk,mode", [(3, 4, 20, 20, 16, "pad"), (2, 8, 81, 81, 64, "causal"),
+                                               (2, 8, 81, 86, 64, "pad"), (2, 2, 5, 128, 32, "none"),
+                                               (1, 8, 80, 80, 64, "pad")])
+def test_attention(ops, B, H, Lq, Lk, dk, mode):
+    d = H * dk
+    qkv = rnd(B * max(Lq, Lk), 3 * d, seed=1)
+    q2, k2, v2 = rnd(B * Lq, d, seed=2), rnd(B * Lk, 2 * d, seed=3), None
+    # q from its own buffer, k/v interleaved in one [B*Lk, 2d] buffer (cross-attention layout)
+    qg, kvg = q2.to(DEV), k2.to(DEV)
+    kview, vview = kvg[:, :d], kvg[:, d:]
+    lens = torch.tensor([Lk - (i * 3) % max(1, Lk // 2) for i in range(B)])
+    if mode == "pad":
+        mask = (torch.arange(Lk)[None, :] < lens[:, None]).to(torch.uint8)          # [B,Lk]
+        mfull = mask[:, None, None, :]
+    elif mode == "causal":
+        pad = (torch.arange(Lk)[None, :] < lens[:, None])
+        mask = (pad[:, None, :] & torch.tril(torch.ones(Lq, Lk, dtype=torch.bool))[None]).to(torch.uint8)
+        mfull = mask[:, None]
+    else:
+        mask, mfull = None, None
+    mg = None if mask is None else mask.to(DEV)
+    o, lse, probs = ops.attn_fwd(qg, kview, vview, d, 2 * d, 2 * d, mg, B, H, Lq, Lk, dk, 0.0, 0, 0, want_probs=True)
+    qd = q2.double().view(B, Lq, H, dk).transpose(1, 2).requires_grad_()
+    kd = k2[:, :d].double().reshape(B, Lk, H, dk).transpose(1, 2).requires_grad_()
+    vd = k2[:, d:].double().reshape(B, Lk, H, dk).transpose(1, 2).requires_grad_()
+    oref, pref = ref_attention(qd, kd, vd, mfull, 1 / math.sqrt(dk))
+    close(probs, pref, 1e-6, 1e-5, "probs")
+    close(o.view(B, Lq, H, dk).transpose(1, 2), oref, 1e-5, 1e-5, "attn out")
+    do = rnd(B * Lq, d, seed=5)
+    oref.backward(do.double().view(B, Lq, H, dk).transpose(1, 2))
+    dq = torch.empty(B * Lq, d, device=DEV)
+    dkv = torch.empty(B * Lk, 2 * d, device=DEV)
+    ops.attn_bwd(qg, kview, vview, d, 2 * d, 2 * d, mg, o, do.to(DEV), lse, dq, dkv[:, :d], dkv[:, d:],
+                 d, 2 * d, 2 * d, B, H, Lq, Lk, dk, 0.0, 0, 0)
+    close(dq.view(B, Lq, H, dk).transpose(1, 2), qd.grad, 2e-5, 1e-4, "dq")
+    close(dkv[:, :d].reshape(B, Lk, H, dk).transpose(1, 2), kd.grad, 2e-5, 1e-4, "dk")
+    close(dkv[:, d:].reshape(B, Lk, H, dk).transpose(1, 2), vd.grad, 2e-5, 1e-4, "dv")
+
+
+def test_attention_dropout(ops):
+    """V = identity recovers the dropped probabilities => the mask; the backward must use it."""
+    B, H, L, dk, p, seed = 2, 2, 48, 64, 0.25, 99
+    d = H * dk
+    q, k = rnd(B * L, d, seed=1), rnd(B * L, d, seed=2)
+    eye = torch.zeros(B, L, H, dk)
+    for i in range(L):
+        eye[:, i, :, i] = 1.0
+    v = eye.view(B * L, d)
+    qg, kg, vg = q.to(DEV), k.to(DEV), v.to(DEV)
+    o, lse, probs = ops.attn_fwd(qg, kg, vg, d, d, d, None, B, H, L, L, dk, p, seed, 3, want_probs=True)
+    pd = o.view(B, L, H, dk).transpose(1, 2)[..., :L].cpu()          # [B,H,L,L] dropped probs
+    pr = probs.cpu()
+    keep = pd != 0
+    assert abs(keep.float().mean().item() - (1 - p)) < 0.02
+    close(pd, torch.where(keep, pr / (1 - p), torch.zeros_like(pr)), 1e-6, 1e-5, "dropped probs")
+    # backward with a generic V
+    v2 = rnd(B * L, d, seed=4)
+    v2g = v2.to(DEV)
+    o2, lse2, _ = ops.attn_fwd(qg, kg, v2g, d, d, d, None, B, H, L, L, dk, p, seed, 3)
+    qd = q.double().view(B, L, H, dk).transpose(1, 2).requires_grad_()
+    kd = k.double().view(B, L, H, dk).transpose(1, 2).requires_grad_()
+    vd = v2.double().view(B, L, H, dk).transpose(1, 2).requires_grad_()
+    oref, _ = ref_attention(qd, kd, vd, None, 1 / math.sqrt(dk), keep.double(), 1 - p)
+    close(o2.view(B, L, H, dk).transpose(1, 2), oref, 1e-5, 1e-5, "dropout attn out")
+    do = rnd(B * L, d, seed=5)
+    oref.backward(do.double().view(B, L, H, dk).transpose(1, 2))
+    dq, dk_, dv = (torch.empty(B * L, d, device=DEV) for _ in range(3))
+    ops.attn_bwd(qg, kg, v2g, d, d, d, None, o2, do.to(DEV), lse2, dq, dk_, dv, d, d, d, B, H, L, L, dk, p, seed, 3)
+    close(dq.view(B, L, H, dk).transpose(1, 2), qd.grad, 3e-5, 1e-4, "dq (dropout)")
+    close(dk_.view(B, L, H, dk).transpose(1, 2), kd.grad, 3e-5, 1e-4, "dk (dropout)")
+    close(dv.view(B, L, H, dk).transpose(1, 2), vd.grad, 3e-5, 1e-4, "dv (dropout)")
+
+
+@pytest.mark.parametrize("n_c", [0, 3])
+def test_embed_pe(ops, n_c):
+    B, S, d, V = 5, 20, 64, 30
+    g = torch.Generator().manual_seed(0)
+    tok = torch.randint(0, V, (B, S), generator=g)
+    table, pe = rnd(V, d, seed=1), rnd(200, d, seed=2)
+    cond = rnd(B, n_c, d, seed=3) if n_c else None
+    out = ops.embed_pe_fwd(tok.to(DEV), table.to(DEV), None if cond is None else cond.to(DEV), pe.to(DEV),
+                           n_c, math.sqrt(d), 0.0, 0, 0)
+    td = table.double().requires_grad_()
+    x = F.embedding(tok, td)
+    cd = None
+    if n_c:
+        cd = cond.double().requires_grad_()
+        x = torch.cat([cd, x], 1)
+    ref = x * math.sqrt(d) + pe.double()[: S + n_c]
+    close(out.view(B, S + n_c, d), ref, 1e-6, 1e-6, "embed fwd")
+    dout = rnd(B * (S + n_c), d, seed=4)
+    ref.backward(dout.double().view(B, S + n_c, d))
+    dtable = torch.empty(V, d, device=DEV)
+    dcond = torch.empty(B, n_c, d, device=DEV) if n_c else None
+    ops.embed_pe_bwd(dout.to(DEV), tok.to(DEV), dtable, dcond, n_c, math.sqrt(d), 0.0, 0, 0)
+    close(dtable, td.grad, 1e-4, 1e-5, "embed dtable")
+    if n_c:
+        close(dcond, cd.grad, 1e-5, 1e-5, "embed dcond")
+    # dropout: fwd mask == bwd mask
+    p = 0.3
+    o2 = ops.embed_pe_fwd(tok.to(DEV), table.to(DEV), None if cond is None else cond.to(DEV), pe.to(DEV),
+                          n_c, math.sqrt(d), p, 5, 11)
+    keep = (o2 != 0).cpu()
+    assert abs(keep.float().mean().item() - (1 - p)) < 0.03
+    ones = torch.ones(B * (S + n_c), d, device=DEV)
+    dt2 = torch.empty(V, d, device=DEV)
+    dc2 = torch.empty(B, n_c, d, device=DEV) if n_c else None
+    ops.embed_pe_bwd(ones, tok.to(DEV), dt2, dc2, n_c, 1.0, p, 5, 11)
+    exp = torch.zeros(V, d, dtype=torch.double)
+    kk = keep.view(B, S + n_c, d)[:, n_c:].double() / (1 - p)
+    exp.index_add_(0, tok.reshape(-1), kk.reshape(-1, d))
+    close(dt2, exp, 1e-4, 1e-5, "embed bwd dropout mask")
+
+
+def test_reparam_kld_ce(ops):
+    n = (7, 23, 16)
+    mu, lv, eps, dz = rnd(*n, seed=1), rnd(*n, seed=2, scale=0.5), rnd(*n, seed=3), rnd(*n, seed=4)
+    z, eo = ops.reparam_fwd(mu.to(DEV), lv.to(DEV), eps.to(DEV), 0, 0)
+    close(z, eps.double() * torch.exp(0.5 * lv.double()) + mu.double(), 1e-6, 1e-6, "z")
+    assert torch.equal(eo.cpu(), eps)
+    dmu, dlv = torch.empty(*n, device=DEV), torch.empty(*n, device=DEV)
+    ext1, ext2 = rnd(*n, seed=5), rnd(*n, seed=6)
+    ops.reparam_bwd(dz.to(DEV), lv.to(DEV), eps.to(DEV), ext1.to(DEV), ext2.to(DEV), dmu, dlv)
+    close(dmu, dz.double() + ext1.double(), 1e-6, 1e-6)
+    close(dlv, 0.5 * dz.double() * eps.double() * torch.exp(0.5 * lv.double()) + ext2.double(), 1e-6, 1e-5)
+    # in-kernel N(0,1)
+    big = torch.zeros(1 << 20, device=DEV)
+    _, e2 = ops.reparam_fwd(big, big, None, 42, 1)
+    assert abs(e2.mean().item()) < 5e-3 and abs(e2.std().item() - 1) < 5e-3
+    assert abs((e2 ** 4).mean().item() - 3) < 0.05
+    # KLD
+    k = ops.kld_fwd(mu.to(DEV), lv.to(DEV))
+    md, ld = mu.double().requires_grad_(), lv.double().requires_grad_()
+    kr = -0.5 * torch.sum(1 + ld - md.pow(2) - ld.exp())
+    close(k, kr, 1e-3, 1e-6, "kld")
+    (0.04 * kr).backward()
+    gm, gl = ops.kld_bwd(mu.to(DEV), lv.to(DEV), torch.tensor(0.04, device=DEV))
+    close(gm, md.grad, 1e-7, 1e-5)
+    close(gl, ld.grad, 1e-7, 1e-5)
+    # CE (sum, ignore pad)
+    rows, V = 333, 30
+    logits = rnd(rows, V, seed=7, scale=2.0)
+    tgt = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(8))
+    tgt[::5] = 1
+    c = ops.ce_fwd(logits.to(DEV), tgt.to(DEV), 1)
+    lg = logits.double().requires_grad_()
+    cr = F.cross_entropy(lg, tgt, ignore_index=1, reduction="sum")
+    close(c, cr, 1e-3, 1e-6, "ce")
+    (1.7 * cr).backward()
+    dl = ops.ce_bwd(logits.to(DEV), tgt.to(DEV), torch.tensor(1.7, device=DEV), 1)
+    close(dl, lg.grad, 1e-6, 1e-5, "ce bwd")
+
+
+def test_adam_matches_torch(ops):
+    n = 10007
+    p0, g = rnd(n, seed=1), rnd(n, seed=2)
+    ref = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=1e-4, betas=(0.9, 0.98), eps=1e-9)
+    pg, m, v = p0.to(DEV).clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 6):
+        gi = g * (1 + 0.1 * step)
+        ref.grad = gi.clone()
+        opt.step()
+        ops.adam_step(pg, gi.to(DEV), m, v, 1e-4, 0.9, 0.98, 1e-9, step)
+    close(pg, ref, 1e-7, 1e-6, "adam params")
+    close(m, opt.state[ref]["exp_avg"], 1e-7, 1e-5)
+    close(v, opt.state[ref]["exp_avg_sq"], 1e-9, 1e-5)
+
+
+def test_small_linear_and_copy_rows(ops):
+    B, K, N = 37, 3, 192
+    x, w, b, dy = rnd(B, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(B, N, seed=4)
+    y = ops.small_linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV))
+    close(y, x.double() @ w.double().t() + b.double(), 1e-6, 1e-6)
+    dw, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+    ops.small_linear_bwd(dy.to(DEV), x.to(DEV), dw, db)
+    close(dw, dy.double().t() @ x.double(), 1e-5, 1e-5)
+    close(db, dy.double().sum(0), 1e-5, 1e-5)
+    # concat [B,3,d] in front of [B,5,d]
+    d = 16
+    a, c = rnd(B, 3, d, seed=5), rnd(B, 5, d, seed=6)
+    dst = torch.empty(B, 8, d, device=DEV)
+    ops.copy_rows(a.to(DEV), 3, 0, dst, 8, 0, B * 3, 3, d)
+    ops.copy_rows(c.to(DEV), 5, 0, dst, 8, 3, B * 5, 5, d)
+    assert torch.equal(dst.cpu(), torch.cat([a, c], 1))
+    s = ops.add(a.to(DEV), a.to(DEV))
+    assert torch.equal(s.cpu(), a + a)
