@@ -1,0 +1,144 @@
+"""Vaetf: unconditioned Transformer-VAE (reference Model/vaetf.py:14-182) on the MI355X
+engine.  Same constructor signature, sub-module names, registration order (=> identical RNG
+consumption at init, identical state_dict keys and Adam state order) and call contract:
+
+    forward(src, trg, src_mask, trg_mask, econds=None, dconds=None)
+        -> (output_prop, output_mol, mu, log_var, z)        [+ attention lists with get_attn]
+    encode(src, src_mask, econds=None) -> (z, mu, log_var)
+    decode(trg, z, src_mask, trg_mask, dconds=None) -> logits
+"""
+import torch
+import torch.nn as nn
+
+from .. import engine, ops
+from ..flat import FlatModelMixin
+from .layers import DecoderLayer, EncoderLayer
+from .modules import Embeddings, Norm, PositionalEncoding, get_clones
+from .sublayers import Sampler
+
+
+class _TrunkParams:
+    """Caches the parameter tuple a trunk hands to its autograd.Function."""
+
+    def trunk_params(self):
+        ps = self.__dict__.get("_trunk_params_cache")
+        if ps is None:
+            ps = tuple(p for n, p in self.named_parameters() if not n.startswith(self._dead_prefixes))
+            self.__dict__["_trunk_params_cache"] = ps
+        return ps
+
+
+class Encoder(nn.Module, _TrunkParams):
+    _dead_prefixes = ("fc_mu", "fc_log_var")  # owned but never used by Vaetf (vaetf.py:26-27)
+
+    def __init__(self, vocab_size, d_model, N, h, dff, latent_dim, nconds, dropout,
+                 variational=True, get_attn=False):
+        super().__init__()
+        self.N, self.nconds, self.variational, self.get_attn = N, nconds, variational, get_attn
+        self.d_model, self.p = d_model, dropout
+        self.embed_sentence = Embeddings(d_model, vocab_size)
+        self.norm = Norm(d_model)
+        self.pe = PositionalEncoding(d_model, dropout=dropout)
+        self.layers = get_clones(EncoderLayer(h, d_model, dff, dropout, get_attn), N)
+        self.fc_mu = nn.Linear(d_model, latent_dim)
+        self.fc_log_var = nn.Linear(d_model, latent_dim)
+        if nconds > 0:
+            self.embed_cond2enc = nn.Linear(nconds, d_model * nconds)
+
+    def trunk(self, src, src_mask, econds):
+        run = engine.Run(self.p, self.training)
+        outs = engine.EncoderFn.apply(self, run, src.contiguous(), ops.to_mask_u8(src_mask), econds,
+                                      self.get_attn, *self.trunk_params())
+        if self.get_attn:
+            return outs[0], list(outs[1:])
+        return outs, None
+
+    def forward(self, src, src_mask, econds):
+        x, attn = self.trunk(src, src_mask, econds)
+        return (x, attn) if self.get_attn else x
+
+
+class Decoder(nn.Module, _TrunkParams):
+    _dead_prefixes = ("\0",)
+
+    def __init__(self, vocab_size, d_model, N, h, dff, latent_dim, nconds, dropout, use_cond2dec,
+                 use_cond2lat, get_attn=False):
+        super().__init__()
+        self.N, self.nconds, self.d_model, self.get_attn = N, nconds, d_model, get_attn
+        self.use_cond2dec, self.use_cond2lat, self.p = use_cond2dec, use_cond2lat, dropout
+        self.embed = Embeddings(d_model, vocab_size)
+        self.pe = PositionalEncoding(d_model, dropout=dropout)
+        self.fc_z = nn.Linear(latent_dim, d_model)
+        self.layers = get_clones(DecoderLayer(h, d_model, dff, dropout, get_attn), N)
+        self.norm = Norm(d_model)
+        if use_cond2dec and nconds > 0:
+            self.embed_cond2dec = nn.Linear(nconds, d_model * nconds)
+        if use_cond2lat and nconds > 0:
+            self.embed_cond2lat = nn.Linear(nconds, d_model * nconds)
+
+    def forward(self, trg, z, src_mask, trg_mask, dconds):
+        run = engine.Run(self.p, self.training)
+        outs = engine.DecoderFn.apply(self, run, trg.contiguous(), z, ops.to_mask_u8(src_mask),
+                                      ops.to_mask_u8(trg_mask), dconds, self.get_attn,
+                                      *self.trunk_params())
+        if self.get_attn:
+            n = self.N
+            return outs[0], list(outs[1:1 + n]), list(outs[1 + n:1 + 2 * n])
+        return outs
+
+
+class Linear(nn.Linear):
+    """nn.Linear parameter holder whose forward runs on the MFMA GEMM (`out`, `prop_fc`)."""
+
+    def forward(self, x):
+        return engine.LinearFn.apply(x, self.weight, self.bias)
+
+
+class Vaetf(FlatModelMixin, nn.Module):
+    def __init__(self, src_vocab, trg_vocab, N=6, d_model=256, dff=2048, h=8, latent_dim=64,
+                 dropout=0.1, nconds=3, use_cond2dec=False, use_cond2lat=False, variational=True,
+                 get_attn=False):
+        super().__init__()
+        self.nconds, self.get_attn = nconds, get_attn
+        self.use_cond2dec, self.use_cond2lat = use_cond2dec, use_cond2lat
+        self.encoder = Encoder(src_vocab, d_model, N, h, dff, latent_dim, nconds, dropout,
+                               variational, get_attn)
+        self.decoder = Decoder(trg_vocab, d_model, N, h, dff, latent_dim, nconds, dropout,
+                               use_cond2dec, use_cond2lat, get_attn)
+        self.sampler = Sampler(d_model, latent_dim, variational)
+        self.out = Linear(d_model, trg_vocab)
+        if use_cond2dec and nconds > 0:
+            self.prop_fc = Linear(trg_vocab, 1)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for _, p in self.named_parameters():        # reference vaetf.py:140-143
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def encode(self, src, src_mask, econds=None):
+        x, _ = self.encoder.trunk(src, src_mask, econds)
+        return self.sampler(x)
+
+    def decode(self, trg, z, src_mask, trg_mask, dconds=None):
+        x = self.decoder(trg, z, src_mask, trg_mask, dconds)
+        if self.get_attn:
+            x = x[0]
+        return self.out(x)
+
+    def forward(self, src, trg, src_mask, trg_mask, econds=None, dconds=None):
+        x, enc_attn = self.encoder.trunk(src, src_mask, econds)
+        z, mu, log_var = self.sampler(x)
+        d = self.decoder(trg, z, src_mask, trg_mask, dconds)
+        if self.get_attn:
+            d, dec_attn_1, dec_attn_2 = d
+        output = self.out(d)
+        if self.use_cond2dec:
+            output_prop = self.prop_fc(output[:, :self.nconds, :])
+            output_mol = output[:, self.nconds:, :]
+        else:
+            output_prop = torch.zeros(output.size(0), self.nconds, 1)   # CPU, as the reference
+            output_mol = output
+        if self.get_attn:
+            return output_prop, output_mol, mu, log_var, z, enc_attn, dec_attn_1, dec_attn_2
+        return output_prop, output_mol, mu, log_var, z

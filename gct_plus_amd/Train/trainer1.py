@@ -1,0 +1,148 @@
+"""Training loop with the reference's contract (Train/trainer1.py:14-255): loss_function,
+KLAnnealer, save_checkpoint, run_epoch, train_model -- same arguments, history keys, log
+line, CSV files and checkpoint dict -- on the HIP loss kernels (K6/K7).
+
+Differences that do not change results: masks are built on the device; the three per-step
+scalars cross to the host in ONE transfer instead of three `.item()` syncs; `np.float`
+(removed from NumPy) is not used."""
+import os
+from functools import reduce
+from time import time
+
+import pandas as pd
+import torch
+import torch.distributed as dist
+
+from .. import engine
+from ..Model.forward_propagation1 import forward_propagation
+
+
+def KLAnnealer(epoch, KLA_ini_beta, KLA_inc_beta, KLA_beg_epoch):
+    return KLA_ini_beta + KLA_inc_beta * ((epoch + 1) - KLA_beg_epoch)
+
+
+def loss_function(beta, preds_prop, preds_mol, ys_cond, ys_mol, mu, log_var, use_cond2dec, pad_id):
+    """RCE = CE(sum, ignore pad); KLD over every latent element; loss = RCE + beta*KLD
+    (+ MSE_sum(prop) with use_cond2dec).  Returns (loss, RCE_mol, RCE_prop, KLD)."""
+    RCE_mol = engine.CrossEntropySumFn.apply(preds_mol, ys_mol, pad_id)
+    KLD = engine.KldFn.apply(mu, log_var)
+    if use_cond2dec:
+        diff = preds_prop - ys_cond          # [B, n_c, 1]: a few hundred floats, host-side glue
+        RCE_prop = (diff * diff).sum()
+        loss = RCE_mol + RCE_prop + beta * KLD
+    else:
+        RCE_prop = torch.zeros(1)
+        loss = RCE_mol + beta * KLD
+    return loss, RCE_mol, RCE_prop, KLD
+
+
+def save_checkpoint(args, model, optimizer, save_path):
+    names = ('N', 'd_model', 'd_ff', 'H', 'latent_dim', 'dropout', 'use_cond2dec', 'use_cond2lat',
+             'variational')
+    hyper = {'nconds': len(args.property_list)}
+    for n in names:
+        hyper[n] = getattr(args, n)
+    torch.save({'model_state_dict': model.state_dict(), 'opt_state_dict': optimizer.state_dict(),
+                'model_params': hyper}, save_path)
+
+
+def warmup_lr(step, d_model, warm):
+    """lr written after step k and used by step k+1 (reference trainer1.py:117-127)."""
+    return float(d_model) ** -0.5 * min(float(step) ** -0.5, float(step) * float(warm) ** -1.5)
+
+
+def run_epoch(args, model, optimizer, dataloader, current_step, beta, LOG, train):
+    n_samples = 0
+    every = max(1, int(getattr(args, 'print_every', 1)))
+    history = {'RCE': [], 'KLD': [], 'LOSS': [], 'BETA': [], 'LR': []}
+    model_cost_time = update_cost_time = 0
+    cost_time = -time()
+    nprop = len(args.property_list)
+    n_batches = len(dataloader)
+    for i, batch in enumerate(dataloader):
+        current_step += 1
+        n_onebatch = batch['src'].size(0)
+        model_cost_time -= time()
+        preds_prop, preds_mol, mu, log_var, _ = forward_propagation[args.model_type](
+            model, batch, args.pad_id, args.use_cond2dec)[:5]
+        model_cost_time += time()
+        ys_cond = batch['dconds'].unsqueeze(2).contiguous().view(-1, nprop, 1) if nprop > 0 else None
+        ys_mol = batch['trg'][:, 1:].contiguous().view(-1)
+        update_cost_time -= time()
+        if train:
+            optimizer.zero_grad(set_to_none=True)
+        loss, RCE_mol, RCE_prop, KLD = loss_function(beta, preds_prop, preds_mol, ys_cond, ys_mol,
+                                                     mu, log_var, args.use_cond2dec, args.pad_id)
+        if train:
+            loss.backward()
+            optimizer.step()
+        update_cost_time += time()
+        lr = None
+        if args.lr_scheduler == "WarmUpDefault":
+            lr = warmup_lr(current_step, args.d_model, args.lr_WarmUpSteps)
+        if train and lr is not None:
+            for g in optimizer.param_groups:
+                g['lr'] = lr
+        current_lr = optimizer.param_groups[-1]['lr']
+        n_samples += n_onebatch
+        rce, kld, tot = torch.stack([RCE_mol.detach(), KLD.detach(), loss.detach()]).tolist()
+        history['RCE'].append(rce / n_onebatch)
+        history['KLD'].append(kld / n_onebatch)
+        history['LOSS'].append(tot / n_onebatch)
+        history['BETA'].append(beta)
+        history['LR'].append(current_lr)
+        if (i + 1) % every == 0:
+            LOG.info(f'{i+1}/{n_batches:<10}\tRCE: {history["RCE"][-1]:.5f}\t'
+                     f'KLD: {history["KLD"][-1]:.5f}\tLOSS: {history["LOSS"][-1]:.5f}\t'
+                     f'TIME(s): {time() + cost_time:.1f}\tMODELTIME(s): {model_cost_time:.1f}\t'
+                     f'UPDATETIME(s): {update_cost_time:.1f}')
+    if train:
+        return history, current_step
+    return history
+
+
+def train_model(args, model, optimizer, train_loader, valid_loader, rank, world_size, LOG):
+    beta = 0
+    current_step = (args.start_epoch - 1) * len(train_loader)
+    for epoch in range(args.start_epoch, args.num_epoch + 1):
+        if world_size > 1 and hasattr(train_loader, 'set_epoch'):
+            train_loader.set_epoch(epoch)
+        LOG.info(f'run epoch: {epoch}')
+        if args.use_KLA:
+            if epoch + 1 >= args.KLA_beg_epoch and beta < args.KLA_max_beta:
+                beta = KLAnnealer(epoch, args.KLA_ini_beta, args.KLA_inc_beta, args.KLA_beg_epoch)
+        else:
+            beta = 1
+        LOG.info(f'training start, epoch: {epoch}')
+        if world_size > 1:
+            dist.barrier()
+        model.train()
+        train_history, current_step = run_epoch(args, model, optimizer, train_loader, current_step,
+                                                beta, LOG, train=True)
+        LOG.info('Save training results...')
+        sfx = f'_r{rank}' if world_size > 1 else ''
+        pd.DataFrame(train_history).to_csv(os.path.join(args.model_folder, f'train_{epoch}{sfx}.csv'))
+        LOG.info(f'validation start, epoch: {epoch}')
+        if world_size > 1:
+            dist.barrier()
+        model.eval()
+        with torch.no_grad():
+            valid_history = run_epoch(args, model, optimizer, valid_loader, current_step, beta, LOG,
+                                      train=False)
+        LOG.info('Save validation results...')
+        pd.DataFrame(valid_history).to_csv(os.path.join(args.model_folder, f'valid_{epoch}{sfx}.csv'))
+        if world_size > 1:
+            dist.barrier()
+        if rank == 0:
+            LOG.info('Save model...')
+            save_checkpoint(args, model, optimizer, os.path.join(args.model_folder, f'model_{epoch}.pt'))
+        if world_size > 1 and rank == 0:
+            for data_type in ('train', 'valid'):
+                his = [pd.read_csv(os.path.join(args.model_folder, f'{data_type}_{epoch}_r{r}.csv'),
+                                   index_col=[0]) for r in range(world_size)]
+                cols = [reduce(lambda x, y: x[[c]] + y[[c]], his) / world_size
+                        for c in ('RCE', 'KLD', 'LOSS')]
+                pd.concat(cols + [his[0]['BETA'], his[0]['LR']], axis=1).to_csv(
+                    os.path.join(args.model_folder, f'{data_type}_{epoch}.csv'))
+        if world_size > 1:
+            dist.barrier()

@@ -100,8 +100,10 @@ extern "C" int gct_embed_pe_fwd(const int64_t* tok, const float* table, const fl
                                 const float* pe, float* out, int B, int S, int n_c, int d,
                                 int vocab, float scale, float p, uint64_t seed, uint32_t site,
                                 void* stream) {
-  GCT_CHECK_ARG(tok && table && pe && out && B >= 0 && S > 0 && d > 0 && vocab > 0 && n_c >= 0,
+  // S == 0: pure "x*scale + pe, dropout" over the cond rows (standalone PositionalEncoding)
+  GCT_CHECK_ARG(pe && out && B >= 0 && S >= 0 && d > 0 && vocab > 0 && n_c >= 0 && S + n_c > 0,
                 "embed_pe_fwd: bad args");
+  GCT_CHECK_ARG(S == 0 || (tok && table), "embed_pe_fwd: tok/table missing");
   GCT_CHECK_ARG(n_c == 0 || cond, "embed_pe_fwd: cond rows requested without a cond buffer");
   GCT_CHECK_ARG(p >= 0.f && p < 1.f, "embed_pe_fwd: dropout p out of range");
   if (B == 0) return GCT_OK;
@@ -121,8 +123,9 @@ int gct_reduce_slabs_seg(const float* slabs, int nslab, int64_t stride, float* d
 extern "C" int gct_embed_pe_bwd(const float* dout, const int64_t* tok, float* dtable, float* dcond,
                                 float* ws, int B, int S, int n_c, int d, int vocab, float scale,
                                 float p, uint64_t seed, uint32_t site, void* stream) {
-  GCT_CHECK_ARG(dout && tok && dtable && ws && B >= 0 && S > 0 && d > 0 && vocab > 0 && n_c >= 0,
+  GCT_CHECK_ARG(dout && ws && B >= 0 && S >= 0 && d > 0 && vocab > 0 && n_c >= 0 && S + n_c > 0,
                 "embed_pe_bwd: bad args");
+  GCT_CHECK_ARG(S == 0 || (tok && dtable), "embed_pe_bwd: tok/dtable missing");
   GCT_CHECK_ARG(n_c == 0 || dcond, "embed_pe_bwd: dcond missing");
   GCT_CHECK_ARG(vocab <= 64, "embed_pe_bwd: vocab %d > 64 unsupported (LDS table)", vocab);
   GCT_CHECK_ARG(p >= 0.f && p < 1.f, "embed_pe_bwd: dropout p out of range");
@@ -137,6 +140,7 @@ extern "C" int gct_embed_pe_bwd(const float* dout, const int64_t* tok, float* dt
                      dout, tok, dcond, ws, B, S, n_c, d, vocab, scale / (1.0f - p),
                      gct_drop_threshold(p), gct_rng_make(seed, site), gpc);
   GCT_LAUNCH_CHECK("embed_pe_bwd");
+  if (S == 0) return GCT_OK;
   const int64_t n = (int64_t)vocab * d;
   return gct_reduce_slabs_seg(ws, chunks, n, dtable, nullptr, nullptr, n, n, st);
 }

@@ -1,0 +1,694 @@
+"""Hand-written forward/backward passes of the GCT-Plus Transformer-VAE on top of the HIP
+kernels (gct_plus_amd.ops).  No PyTorch arithmetic runs here: torch is used for device
+memory (caching allocator), streams and the autograd *boundary* -- one autograd.Function per
+trunk (encoder, sampler, decoder, linear, losses); inside a trunk the backward is explicit,
+so residual-gradient joins, the 6-way accumulation of the encoder-memory gradient and the
+dropout masks are handled by kernels/epilogues instead of autograd nodes.
+
+Reference semantics (file:line relative to /root/reference):
+  encoder layer   Model/layers.py:20-38   (residuals start from the NORMALISED x)
+  decoder layer   Model/layers.py:56-82   (standard pre-norm)
+  MHA             Model/sublayers.py:61-74, attention() :29-41
+  FFN             Model/sublayers.py:85-89
+  encoder/decoder Model/vaetf.py:32-54, 79-114 ; Model/cvaetf.py:35-61, 93-133
+  sampler         Model/sublayers.py:14-26
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+from . import ops
+
+_SEED = {"base": None, "ctr": 0}
+
+
+def next_seed() -> int:
+    """Fresh 64-bit dropout/eps seed per trunk call, derived from torch.manual_seed()."""
+    if _SEED["base"] != torch.initial_seed():
+        _SEED["base"] = torch.initial_seed()
+        _SEED["ctr"] = 0
+    _SEED["ctr"] += 1
+    return (_SEED["base"] * 0x9E3779B97F4A7C15 + _SEED["ctr"] * 0xD1B54A32D192ED03) & ((1 << 64) - 1)
+
+
+class Run:
+    """Per-call dropout context: probability, seed and a site counter (every dropout
+    application in the trunk gets its own Philox stream)."""
+
+    def __init__(self, p: float, training: bool):
+        self.p = float(p) if training else 0.0
+        self.seed = next_seed() if self.p > 0 else 0
+        self._site = 0
+
+    def site(self) -> int:
+        self._site += 1
+        return self._site
+
+
+class GradSink:
+    """Where parameter gradients are written.  Parameters of a flattened model carry
+    `_gct_gview` (a view into the model's flat gradient buffer); the kernels write straight
+    into it and autograd adopts the view as .grad (zero copies).  If .grad already aliases
+    that view (no zero_grad(set_to_none=True) since the last backward) a temporary is used so
+    accumulation semantics stay correct."""
+
+    def __init__(self):
+        self.out = {}
+
+    def __call__(self, p: torch.nn.Parameter) -> torch.Tensor:
+        t = self.out.get(p)
+        if t is None:
+            v = getattr(p, "_gct_gview", None)
+            if v is not None and (p.grad is None or p.grad.data_ptr() != v.data_ptr()):
+                t = v
+            else:
+                t = torch.empty_like(p)
+            self.out[p] = t
+        return t
+
+    def collect(self, params):
+        return tuple(self.out.get(p) for p in params)
+
+
+def _empty(rows, cols, like):
+    return torch.empty(rows, cols, dtype=torch.float32, device=like.device)
+
+
+# ------------------------------------------------------------------------------------- MHA
+def mha_fwd(run: Run, m, xq, xkv, B, Lq, Lk, mask_u8, resid, want_probs=False):
+    """m: MultiHeadAttention module (q_linear, k_linear, v_linear, out).  xq [B*Lq,d],
+    xkv [B*Lk,d] (the same tensor object for self-attention).  With `resid` the output
+    projection fuses  resid + dropout(.)  (the layer's dropout_k + residual add)."""
+    d, H = m.d_model, m.h
+    dk = d // H
+    self_attn = xkv is xq
+    if self_attn:
+        qkv = _empty(B * Lq, 3 * d, xq)
+        ops.linear_fwd(xq, [m.q_linear.weight, m.k_linear.weight, m.v_linear.weight],
+                       [m.q_linear.bias, m.k_linear.bias, m.v_linear.bias],
+                       [qkv, qkv[:, d:], qkv[:, 2 * d:]], 3 * d)
+        q, k, v, ldq, ldkv = qkv, qkv[:, d:], qkv[:, 2 * d:], 3 * d, 3 * d
+        qb, kvb = qkv, None
+    else:
+        qb = _empty(B * Lq, d, xq)
+        ops.linear_fwd(xq, [m.q_linear.weight], [m.q_linear.bias], [qb], d)
+        kvb = _empty(B * Lk, 2 * d, xkv)
+        ops.linear_fwd(xkv, [m.k_linear.weight, m.v_linear.weight],
+                       [m.k_linear.bias, m.v_linear.bias], [kvb, kvb[:, d:]], 2 * d)
+        q, k, v, ldq, ldkv = qb, kvb, kvb[:, d:], d, 2 * d
+    site_p = run.site()
+    o, lse, probs = ops.attn_fwd(q, k, v, ldq, ldkv, ldkv, mask_u8, B, H, Lq, Lk, dk, run.p,
+                                 run.seed, site_p, want_probs=want_probs)
+    y = _empty(B * Lq, d, xq)
+    site_o = run.site()
+    if resid is not None:
+        ops.linear_fwd(o, [m.out.weight], [m.out.bias], [y], d, epi=ops.EPI_DROP_RESID,
+                       resid=resid, p=run.p, seed=run.seed, site=site_o)
+    else:
+        ops.linear_fwd(o, [m.out.weight], [m.out.bias], [y], d)
+    saved = (xq, xkv, qb, kvb, o, lse, mask_u8, B, Lq, Lk, site_p, site_o, resid is not None)
+    return y, saved, probs
+
+
+def mha_bwd(run: Run, m, saved, dy, G: GradSink, dxq_out, depi_q, dxkv_out=None,
+            depi_kv=ops.DEPI_STORE):
+    """dy: gradient w.r.t. the block output (resid + dropout(out(o)) or out(o)).
+    Writes dW/db through G, d(xq) into dxq_out (epilogue depi_q) and, for cross-attention,
+    d(xkv) into dxkv_out (epilogue depi_kv).  The identity path to `resid` is the caller's."""
+    xq, xkv, qb, kvb, o, lse, mask_u8, B, Lq, Lk, site_p, site_o, fused = saved
+    d, H = m.d_model, m.h
+    dk = d // H
+    Mq, Mk = B * Lq, B * Lk
+    g = ops.dropout_bwd(dy, run.p, run.seed, site_o) if (fused and run.p > 0) else dy
+    ops.linear_wgrad([g], d, o, [G(m.out.weight)], [G(m.out.bias)])
+    do = _empty(Mq, d, dy)
+    ops.linear_dgrad([g], d, Mq, [m.out.weight], do)
+    if kvb is None:  # self-attention: fused [q|k|v]
+        dqkv = _empty(Mq, 3 * d, dy)
+        ops.attn_bwd(qb, qb[:, d:], qb[:, 2 * d:], 3 * d, 3 * d, 3 * d, mask_u8, o, do, lse, dqkv,
+                     dqkv[:, d:], dqkv[:, 2 * d:], 3 * d, 3 * d, 3 * d, B, H, Lq, Lk, dk, run.p,
+                     run.seed, site_p)
+        segs = [dqkv, dqkv[:, d:], dqkv[:, 2 * d:]]
+        ops.linear_wgrad(segs, 3 * d, xq,
+                         [G(m.q_linear.weight), G(m.k_linear.weight), G(m.v_linear.weight)],
+                         [G(m.q_linear.bias), G(m.k_linear.bias), G(m.v_linear.bias)])
+        ops.linear_dgrad(segs, 3 * d, Mq,
+                         [m.q_linear.weight, m.k_linear.weight, m.v_linear.weight], dxq_out,
+                         depi=depi_q)
+    else:
+        dq = _empty(Mq, d, dy)
+        dkv = _empty(Mk, 2 * d, dy)
+        ops.attn_bwd(qb, kvb, kvb[:, d:], d, 2 * d, 2 * d, mask_u8, o, do, lse, dq, dkv, dkv[:, d:],
+                     d, 2 * d, 2 * d, B, H, Lq, Lk, dk, run.p, run.seed, site_p)
+        ops.linear_wgrad([dq], d, xq, [G(m.q_linear.weight)], [G(m.q_linear.bias)])
+        ops.linear_wgrad([dkv, dkv[:, d:]], 2 * d, xkv,
+                         [G(m.k_linear.weight), G(m.v_linear.weight)],
+                         [G(m.k_linear.bias), G(m.v_linear.bias)])
+        ops.linear_dgrad([dq], d, Mq, [m.q_linear.weight], dxq_out, depi=depi_q)
+        if dxkv_out is not None:
+            ops.linear_dgrad([dkv, dkv[:, d:]], 2 * d, Mk, [m.k_linear.weight, m.v_linear.weight],
+                             dxkv_out, depi=depi_kv)
+
+
+# ------------------------------------------------------------------------------------- FFN
+def ffn_fwd(run: Run, ff, x, resid):
+    M, d = x.shape
+    dff = ff.linear_1.weight.shape[0]
+    pre = _empty(M, dff, x)
+    hdn = _empty(M, dff, x)
+    site_h = run.site()
+    ops.linear_fwd(x, [ff.linear_1.weight], [ff.linear_1.bias], [hdn], dff, epi=ops.EPI_GELU_DROP,
+                   pre=pre, p=run.p, seed=run.seed, site=site_h)
+    y = _empty(M, d, x)
+    site_o = run.site()
+    if resid is not None:
+        ops.linear_fwd(hdn, [ff.linear_2.weight], [ff.linear_2.bias], [y], d,
+                       epi=ops.EPI_DROP_RESID, resid=resid, p=run.p, seed=run.seed, site=site_o)
+    else:
+        ops.linear_fwd(hdn, [ff.linear_2.weight], [ff.linear_2.bias], [y], d)
+    return y, (x, pre, hdn, site_h, site_o, resid is not None)
+
+
+def ffn_bwd(run: Run, ff, saved, dy, G: GradSink, dx_out, depi):
+    x, pre, hdn, site_h, site_o, fused = saved
+    M, d = x.shape
+    dff = pre.shape[1]
+    g = ops.dropout_bwd(dy, run.p, run.seed, site_o) if (fused and run.p > 0) else dy
+    ops.linear_wgrad([g], d, hdn, [G(ff.linear_2.weight)], [G(ff.linear_2.bias)])
+    dpre = _empty(M, dff, dy)
+    ops.linear_dgrad([g], d, M, [ff.linear_2.weight], dpre, depi=ops.DEPI_GELU_BWD, pre=pre,
+                     p=run.p, seed=run.seed, site=site_h)
+    ops.linear_wgrad([dpre], dff, x, [G(ff.linear_1.weight)], [G(ff.linear_1.bias)])
+    ops.linear_dgrad([dpre], dff, M, [ff.linear_1.weight], dx_out, depi=depi)
+
+
+# ---------------------------------------------------------------------------------- layers
+def enc_layer_fwd(run: Run, layer, x_in, B, L, mask_u8, want_probs=False):
+    n1, m1, r1 = ops.norm_fwd(x_in, layer.norm_1.alpha, layer.norm_1.bias, layer.norm_1.eps)
+    a, sv_a, probs = mha_fwd(run, layer.attn, n1, n1, B, L, L, mask_u8, n1, want_probs)
+    n2, m2, r2 = ops.norm_fwd(a, layer.norm_2.alpha, layer.norm_2.bias, layer.norm_2.eps)
+    out, sv_f = ffn_fwd(run, layer.ff, n2, n2)
+    return out, (x_in, m1, r1, sv_a, a, m2, r2, sv_f), probs
+
+
+def enc_layer_bwd(run: Run, layer, saved, g, G: GradSink):
+    """g: mutable [M,d] gradient buffer w.r.t. the layer output; returns d(x_in) in g."""
+    x_in, m1, r1, sv_a, a, m2, r2, sv_f = saved
+    # out = n2 + drop(ffn(n2))  =>  d(n2) = g + ffn'(g): the W1 dgrad accumulates into g
+    ffn_bwd(run, layer.ff, sv_f, g, G, g, ops.DEPI_ACCUM)
+    ops.norm_bwd(g, a, layer.norm_2.alpha, m2, r2, G(layer.norm_2.alpha), G(layer.norm_2.bias),
+                 out=g, eps=layer.norm_2.eps)
+    # a = n1 + drop(attn(n1))
+    mha_bwd(run, layer.attn, sv_a, g, G, g, ops.DEPI_ACCUM)
+    ops.norm_bwd(g, x_in, layer.norm_1.alpha, m1, r1, G(layer.norm_1.alpha), G(layer.norm_1.bias),
+                 out=g, eps=layer.norm_1.eps)
+    return g
+
+
+def dec_layer_fwd(run: Run, layer, x, e, B, T, Lk, src_mask_u8, trg_mask_u8, want_probs=False):
+    x2, m1, r1 = ops.norm_fwd(x, layer.norm_1.alpha, layer.norm_1.bias, layer.norm_1.eps)
+    xa, sv1, p1 = mha_fwd(run, layer.attn_1, x2, x2, B, T, T, trg_mask_u8, x, want_probs)
+    x2, m2, r2 = ops.norm_fwd(xa, layer.norm_2.alpha, layer.norm_2.bias, layer.norm_2.eps)
+    xb, sv2, p2 = mha_fwd(run, layer.attn_2, x2, e, B, T, Lk, src_mask_u8, xa, want_probs)
+    x2, m3, r3 = ops.norm_fwd(xb, layer.norm_3.alpha, layer.norm_3.bias, layer.norm_3.eps)
+    xc, svf = ffn_fwd(run, layer.ff, x2, xb)
+    return xc, (x, m1, r1, sv1, xa, m2, r2, sv2, xb, m3, r3, svf), p1, p2
+
+
+def dec_layer_bwd(run: Run, layer, saved, g, de, first_de, G: GradSink):
+    x, m1, r1, sv1, xa, m2, r2, sv2, xb, m3, r3, svf = saved
+    t = torch.empty_like(g)
+    ffn_bwd(run, layer.ff, svf, g, G, t, ops.DEPI_STORE)
+    ops.norm_bwd(t, xb, layer.norm_3.alpha, m3, r3, G(layer.norm_3.alpha), G(layer.norm_3.bias),
+                 dres=g, out=g, eps=layer.norm_3.eps)
+    mha_bwd(run, layer.attn_2, sv2, g, G, t, ops.DEPI_STORE, de,
+            ops.DEPI_STORE if first_de else ops.DEPI_ACCUM)
+    ops.norm_bwd(t, xa, layer.norm_2.alpha, m2, r2, G(layer.norm_2.alpha), G(layer.norm_2.bias),
+                 dres=g, out=g, eps=layer.norm_2.eps)
+    mha_bwd(run, layer.attn_1, sv1, g, G, t, ops.DEPI_STORE)
+    ops.norm_bwd(t, x, layer.norm_1.alpha, m1, r1, G(layer.norm_1.alpha), G(layer.norm_1.bias),
+                 dres=g, out=g, eps=layer.norm_1.eps)
+    return g
+
+
+# ---------------------------------------------------------------------------------- trunks
+def _pe2d(pe_mod, L):
+    pe = pe_mod.pe
+    if L > pe.shape[1]:
+        raise ValueError(f"sequence length {L} exceeds the positional table ({pe.shape[1]})")
+    return pe[0]
+
+
+def encoder_trunk_fwd(enc, run: Run, src, mask_u8, econds, want_probs=False):
+    """Model/vaetf.py:32-54 (up to the final Norm).  Returns x [B, n_c+S, d] and saved state."""
+    B, S = src.shape
+    d, nc = enc.d_model, enc.nconds
+    cond = None
+    if nc > 0:
+        if econds is None:
+            raise ValueError("econds required when nconds > 0")          # vaetf.py:36
+        cond = ops.small_linear_fwd(econds.contiguous(), enc.embed_cond2enc.weight,
+                                    enc.embed_cond2enc.bias)
+    L = S + nc
+    site_pe = run.site()
+    x = ops.embed_pe_fwd(src, enc.embed_sentence.embed.weight, cond, _pe2d(enc.pe, L), nc,
+                         math.sqrt(d), run.p, run.seed, site_pe)
+    lsv, probs = [], []
+    for layer in enc.layers:
+        x, sv, pr = enc_layer_fwd(run, layer, x, B, L, mask_u8, want_probs)
+        lsv.append(sv)
+        probs.append(pr)
+    y, mean, rstd = ops.norm_fwd(x, enc.norm.alpha, enc.norm.bias, enc.norm.eps)
+    return y.view(B, L, d), (src, econds, site_pe, lsv, x, mean, rstd, B, L), probs
+
+
+def encoder_trunk_bwd(enc, run: Run, saved, dy, G: GradSink):
+    src, econds, site_pe, lsv, x_last, mean, rstd, B, L = saved
+    d, nc = enc.d_model, enc.nconds
+    g = dy.reshape(B * L, d).clone()
+    ops.norm_bwd(g, x_last, enc.norm.alpha, mean, rstd, G(enc.norm.alpha), G(enc.norm.bias), out=g,
+                 eps=enc.norm.eps)
+    for layer, sv in zip(reversed(enc.layers), reversed(lsv)):
+        g = enc_layer_bwd(run, layer, sv, g, G)
+    dcond = torch.empty(B, nc * d, dtype=torch.float32, device=g.device) if nc > 0 else None
+    ops.embed_pe_bwd(g, src, G(enc.embed_sentence.embed.weight), dcond, nc, math.sqrt(d), run.p,
+                     run.seed, site_pe)
+    if nc > 0:
+        ops.small_linear_bwd(dcond, econds.contiguous(), G(enc.embed_cond2enc.weight),
+                             G(enc.embed_cond2enc.bias))
+
+
+def decoder_trunk_fwd(dec, run: Run, trg, z, src_mask_u8, trg_mask_u8, dconds, want_probs=False):
+    """Model/vaetf.py:79-114.  z [B, L_e, latent]."""
+    B, T0 = trg.shape
+    d, nc = dec.d_model, dec.nconds
+    Le, lat = z.shape[1], z.shape[2]
+    z2 = z.reshape(B * Le, lat)
+    c2d = dec.use_cond2dec and nc > 0
+    c2l = (not c2d) and dec.use_cond2lat and nc > 0
+    cond_x = None
+    if c2d:
+        cond_x = ops.small_linear_fwd(dconds.contiguous(), dec.embed_cond2dec.weight,
+                                      dec.embed_cond2dec.bias)
+    T = T0 + (nc if c2d else 0)
+    site_pe = run.site()
+    x = ops.embed_pe_fwd(trg, dec.embed.embed.weight, cond_x, _pe2d(dec.pe, T), nc if c2d else 0,
+                         math.sqrt(d), run.p, run.seed, site_pe)
+    ez = _empty(B * Le, d, z2)
+    ops.linear_fwd(z2, [dec.fc_z.weight], [dec.fc_z.bias], [ez], d)
+    Lk = Le
+    e = ez
+    if c2l:
+        Lk = Le + nc
+        cl = ops.small_linear_fwd(dconds.contiguous(), dec.embed_cond2lat.weight,
+                                  dec.embed_cond2lat.bias)                     # [B, nc*d]
+        e = _empty(B * Lk, d, z2)
+        ops.copy_rows(cl, nc, 0, e, Lk, 0, B * nc, nc, d)
+        ops.copy_rows(ez, Le, 0, e, Lk, nc, B * Le, Le, d)
+        if src_mask_u8 is not None:                                            # vaetf.py:95-98
+            ones = torch.ones(B, nc, dtype=torch.uint8, device=src_mask_u8.device)
+            src_mask_u8 = torch.cat([ones, src_mask_u8.view(B, Le)], dim=1).contiguous()
+    lsv, p1s, p2s = [], [], []
+    for layer in dec.layers:
+        x, sv, p1, p2 = dec_layer_fwd(run, layer, x, e, B, T, Lk, src_mask_u8, trg_mask_u8,
+                                      want_probs)
+        lsv.append(sv)
+        p1s.append(p1)
+        p2s.append(p2)
+    y, mean, rstd = ops.norm_fwd(x, dec.norm.alpha, dec.norm.bias, dec.norm.eps)
+    saved = (trg, z2, dconds, site_pe, lsv, x, mean, rstd, B, T, Le, Lk, c2d, c2l)
+    return y.view(B, T, d), saved, p1s, p2s
+
+
+def decoder_trunk_bwd(dec, run: Run, saved, dy, G: GradSink, need_dz=True):
+    trg, z2, dconds, site_pe, lsv, x_last, mean, rstd, B, T, Le, Lk, c2d, c2l = saved
+    d, nc = dec.d_model, dec.nconds
+    g = dy.reshape(B * T, d).clone()
+    ops.norm_bwd(g, x_last, dec.norm.alpha, mean, rstd, G(dec.norm.alpha), G(dec.norm.bias), out=g,
+                 eps=dec.norm.eps)
+    de = _empty(B * Lk, d, g)
+    first = True
+    for layer, sv in zip(reversed(dec.layers), reversed(lsv)):
+        g = dec_layer_bwd(run, layer, sv, g, de, first, G)
+        first = False
+    if len(dec.layers) == 0:
+        de.zero_()
+    # embedding side
+    dcx = torch.empty(B, nc * d, dtype=torch.float32, device=g.device) if c2d else None
+    ops.embed_pe_bwd(g, trg, G(dec.embed.embed.weight), dcx, nc if c2d else 0, math.sqrt(d), run.p,
+                     run.seed, site_pe)
+    if c2d:
+        ops.small_linear_bwd(dcx, dconds.contiguous(), G(dec.embed_cond2dec.weight),
+                             G(dec.embed_cond2dec.bias))
+    # memory side
+    dez = de
+    if c2l:
+        dcl = torch.empty(B, nc * d, dtype=torch.float32, device=g.device)
+        ops.copy_rows(de, Lk, 0, dcl, nc, 0, B * nc, nc, d)
+        ops.small_linear_bwd(dcl, dconds.contiguous(), G(dec.embed_cond2lat.weight),
+                             G(dec.embed_cond2lat.bias))
+        dez = _empty(B * Le, d, g)
+        ops.copy_rows(de, Lk, nc, dez, Le, 0, B * Le, Le, d)
+    ops.linear_wgrad([dez], d, z2, [G(dec.fc_z.weight)], [G(dec.fc_z.bias)])
+    dz = None
+    if need_dz:
+        dz = _empty(B * Le, z2.shape[1], g)
+        ops.linear_dgrad([dez], d, B * Le, [dec.fc_z.weight], dz)
+        dz = dz.view(B, Le, -1)
+    return dz
+
+
+# ------------------------------------------------------------------------ autograd boundary
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+class EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, run, src, mask_u8, econds, want_probs, *params):
+        y, saved, probs = encoder_trunk_fwd(enc, run, src, mask_u8, econds, want_probs)
+        ctx.enc, ctx.run, ctx.saved, ctx.params = enc, run, saved, params
+        if want_probs:
+            for p in probs:
+                ctx.mark_non_differentiable(p)
+            return (y, *probs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, *unused):
+        G = GradSink()
+        encoder_trunk_bwd(ctx.enc, ctx.run, ctx.saved, _f32c(dy), G)
+        ctx.saved = None
+        return (None,) * 6 + G.collect(ctx.params)
+
+
+class DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dec, run, trg, z, src_mask_u8, trg_mask_u8, dconds, want_probs, *params):
+        y, saved, p1, p2 = decoder_trunk_fwd(dec, run, trg, _f32c(z), src_mask_u8, trg_mask_u8,
+                                             dconds, want_probs)
+        ctx.dec, ctx.run, ctx.saved, ctx.params = dec, run, saved, params
+        ctx.need_dz = z.requires_grad
+        if want_probs:
+            for p in p1 + p2:
+                ctx.mark_non_differentiable(p)
+            return (y, *p1, *p2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, *unused):
+        G = GradSink()
+        dz = decoder_trunk_bwd(ctx.dec, ctx.run, ctx.saved, _f32c(dy), G, ctx.need_dz)
+        ctx.saved = None
+        return (None, None, None, dz, None, None, None, None) + G.collect(ctx.params)
+
+
+class SamplerFn(torch.autograd.Function):
+    """mu = fc_mu(x), log_var = fc_log_var(x) as ONE segmented GEMM, then the
+    reparameterisation (Model/sublayers.py:22-26, Model/cvaetf.py:55-69)."""
+
+    @staticmethod
+    def forward(ctx, x, w_mu, b_mu, w_lv, b_lv, eps, variational):
+        B, L, d = x.shape
+        lat = w_mu.shape[0]
+        x2 = _f32c(x).view(B * L, d)
+        mu = _empty(B * L, lat, x2)
+        lv = _empty(B * L, lat, x2)
+        ops.linear_fwd(x2, [w_mu, w_lv], [b_mu, b_lv], [mu, lv], lat)
+        if variational:
+            z, eps_used = ops.reparam_fwd(mu, lv, None if eps is None else _f32c(eps).view(B * L, lat),
+                                          next_seed(), 0)
+        else:
+            z, eps_used = mu, None
+        ctx.save_for_backward(x2, w_mu, w_lv, lv, eps_used if eps_used is not None else lv)
+        ctx.variational = variational
+        ctx.shape = (B, L, d, lat)
+        ctx.params = (w_mu, b_mu, w_lv, b_lv)
+        shp = (B, L, lat)
+        if variational:
+            return z.view(shp), mu.view(shp), lv.view(shp)
+        return mu.view(shp), mu.view(shp).clone(), lv.view(shp)
+
+    @staticmethod
+    def backward(ctx, dz, dmu, dlv):
+        x2, w_mu, w_lv, lv, eps = ctx.saved_tensors
+        B, L, d, lat = ctx.shape
+        M = B * L
+        zeros = None
+        def flat(t):
+            return None if t is None else _f32c(t).view(M, lat)
+        dz, dmu, dlv = flat(dz), flat(dmu), flat(dlv)
+        gmu = _empty(M, lat, x2)
+        glv = _empty(M, lat, x2)
+        if ctx.variational:
+            if dz is None:
+                dz = torch.zeros(M, lat, dtype=torch.float32, device=x2.device)
+            ops.reparam_bwd(dz, lv, eps, dmu, dlv, gmu, glv)
+        else:
+            z0 = torch.zeros(M, lat, dtype=torch.float32, device=x2.device)
+            a = dz if dz is not None else z0
+            b = dmu if dmu is not None else z0
+            ops.add(a, b, out=gmu)
+            glv = dlv if dlv is not None else z0
+        G = GradSink()
+        w_mu_p, b_mu_p, w_lv_p, b_lv_p = ctx.params
+        ops.linear_wgrad([gmu, glv], lat, x2, [G(w_mu_p), G(w_lv_p)], [G(b_mu_p), G(b_lv_p)])
+        dx = _empty(M, d, x2)
+        ops.linear_dgrad([gmu, glv], lat, M, [w_mu, w_lv], dx)
+        return (dx.view(B, L, d),) + G.collect(ctx.params) + (None, None)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the MFMA GEMM (Model/vaetf.py:169 `out`, :172 `prop_fc`)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        shp = x.shape
+        x2 = _f32c(x).reshape(-1, shp[-1])
+        y = _empty(x2.shape[0], w.shape[0], x2)
+        ops.linear_fwd(x2, [w], [b], [y], w.shape[0])
+        ctx.save_for_backward(x2, w)
+        ctx.params = (w, b)
+        ctx.shp = shp
+        return y.view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        N = w.shape[0]
+        dy2 = _f32c(dy).reshape(-1, N)
+        G = GradSink()
+        wp, bp = ctx.params
+        ops.linear_wgrad([dy2], N, x2, [G(wp)], [G(bp) if bp is not None else None])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty(x2.shape[0], x2.shape[1], x2)
+            ops.linear_dgrad([dy2], N, x2.shape[0], [w], dx)
+            dx = dx.view(ctx.shp)
+        return dx, G.out.get(wp), G.out.get(bp) if bp is not None else None
+
+
+class CrossEntropySumFn(torch.autograd.Function):
+    """Train/trainer1.py:21-22."""
+
+    @staticmethod
+    def forward(ctx, logits, target, pad_id):
+        l2 = _f32c(logits).reshape(-1, logits.shape[-1])
+        t = target.reshape(-1).contiguous()
+        ctx.save_for_backward(l2, t)
+        ctx.pad_id, ctx.shp = int(pad_id), logits.shape
+        return ops.ce_fwd(l2, t, int(pad_id))
+
+    @staticmethod
+    def backward(ctx, g):
+        l2, t = ctx.saved_tensors
+        return ops.ce_bwd(l2, t, _f32c(g), ctx.pad_id).view(ctx.shp), None, None
+
+
+class KldFn(torch.autograd.Function):
+    """Train/trainer1.py:23."""
+
+    @staticmethod
+    def forward(ctx, mu, log_var):
+        m, l = _f32c(mu), _f32c(log_var)
+        ctx.save_for_backward(m, l)
+        return ops.kld_fwd(m, l)
+
+    @staticmethod
+    def backward(ctx, g):
+        m, l = ctx.saved_tensors
+        dmu, dlv = ops.kld_bwd(m, l, _f32c(g))
+        return dmu, dlv
+
+
+class NormFn(torch.autograd.Function):
+    """Standalone Norm module call (Model/modules.py:92-95)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, bias, eps):
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        y, mean, rstd = ops.norm_fwd(x2, alpha, bias, eps)
+        ctx.save_for_backward(x2, alpha, mean, rstd)
+        ctx.params, ctx.eps, ctx.shp = (alpha, bias), eps, x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, alpha, mean, rstd = ctx.saved_tensors
+        G = GradSink()
+        a, b = ctx.params
+        dx = ops.norm_bwd(_f32c(dy).reshape(x2.shape), x2, alpha, mean, rstd, G(a), G(b), eps=ctx.eps)
+        return dx.view(ctx.shp), G.out[a], G.out[b], None
+
+
+# ----------------------------------------------------- standalone sub-module calls (rare)
+class EmbedFn(torch.autograd.Function):
+    """Embeddings.forward alone: the K1 kernel with scale 1 and a zero positional table."""
+
+    @staticmethod
+    def forward(ctx, tok, table):
+        B, S = tok.shape
+        d = table.shape[1]
+        zeros = torch.zeros(S, d, dtype=torch.float32, device=table.device)
+        out = ops.embed_pe_fwd(tok.contiguous(), table, None, zeros, 0, 1.0, 0.0, 0, 0)
+        ctx.tok, ctx.param = tok.contiguous(), table
+        return out.view(B, S, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        G = GradSink()
+        d = ctx.param.shape[1]
+        ops.embed_pe_bwd(_f32c(dy).reshape(-1, d), ctx.tok, G(ctx.param), None, 0, 1.0, 0.0, 0, 0)
+        return None, G.out[ctx.param]
+
+
+class PosEncFn(torch.autograd.Function):
+    """PositionalEncoding.forward alone: x*sqrt(d) + pe[:L], dropout -- the K1 kernel with
+    zero token columns (every row is a 'cond' row)."""
+
+    @staticmethod
+    def forward(ctx, x, pe, scale, run):
+        B, L, d = x.shape
+        x2 = _f32c(x).view(B, L * d)
+        site = run.site()
+        dummy_tok = torch.zeros(B, 0, dtype=torch.int64, device=x.device)
+        out = ops.embed_pe_fwd(dummy_tok, None, x2, _pe2d_raw(pe, L), L, scale, run.p, run.seed,
+                               site, d=d)
+        ctx.cfg = (B, L, d, scale, run, site)
+        return out.view(B, L, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, L, d, scale, run, site = ctx.cfg
+        dx = torch.empty(B, L * d, dtype=torch.float32, device=dy.device)
+        dummy_tok = torch.zeros(B, 0, dtype=torch.int64, device=dy.device)
+        ops.embed_pe_bwd(_f32c(dy).reshape(B * L, d), dummy_tok, None, dx, L, scale, run.p,
+                         run.seed, site, d=d)
+        return dx.view(B, L, d), None, None, None
+
+
+def _pe2d_raw(pe, L):
+    if L > pe.shape[1]:
+        raise ValueError(f"sequence length {L} exceeds the positional table ({pe.shape[1]})")
+    return pe[0]
+
+
+def _flat3(x):
+    B, L, d = x.shape
+    return _f32c(x).view(B * L, d), B, L, d
+
+
+class MhaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, m, run, q, kv, mask_u8, want_probs, *params):
+        xq, B, Lq, d = _flat3(q)
+        if kv is None:
+            xkv, Lk = xq, Lq
+        else:
+            xkv, _, Lk, _ = _flat3(kv)
+        y, saved, probs = mha_fwd(run, m, xq, xkv, B, Lq, Lk, mask_u8, None, want_probs)
+        ctx.m, ctx.run, ctx.saved, ctx.params = m, run, saved, params
+        ctx.shapes = (B, Lq, Lk, d, kv is not None)
+        if want_probs:
+            ctx.mark_non_differentiable(probs)
+            return y.view(B, Lq, d), probs
+        return (y.view(B, Lq, d),)
+
+    @staticmethod
+    def backward(ctx, dy, *unused):
+        B, Lq, Lk, d, cross = ctx.shapes
+        G = GradSink()
+        dxq = torch.empty(B * Lq, d, dtype=torch.float32, device=dy.device)
+        dxkv = torch.empty(B * Lk, d, dtype=torch.float32, device=dy.device) if cross else None
+        mha_bwd(ctx.run, ctx.m, ctx.saved, _f32c(dy).reshape(B * Lq, d), G, dxq, ops.DEPI_STORE,
+                dxkv, ops.DEPI_STORE)
+        ctx.saved = None
+        return (None, None, dxq.view(B, Lq, d), dxkv.view(B, Lk, d) if cross else None, None,
+                None) + G.collect(ctx.params)
+
+
+class FfnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ff, run, x, *params):
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        y, saved = ffn_fwd(run, ff, x2, None)
+        ctx.ff, ctx.run, ctx.saved, ctx.params, ctx.shp = ff, run, saved, params, x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        G = GradSink()
+        dy2 = _f32c(dy).reshape(-1, dy.shape[-1])
+        dx = torch.empty_like(dy2)
+        ffn_bwd(ctx.run, ctx.ff, ctx.saved, dy2, G, dx, ops.DEPI_STORE)
+        ctx.saved = None
+        return (None, None, dx.view(ctx.shp)) + G.collect(ctx.params)
+
+
+class EncLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, layer, run, x, mask_u8, want_probs, *params):
+        x2, B, L, d = _flat3(x)
+        y, saved, probs = enc_layer_fwd(run, layer, x2, B, L, mask_u8, want_probs)
+        ctx.layer, ctx.run, ctx.saved, ctx.params, ctx.shp = layer, run, saved, params, (B, L, d)
+        if want_probs:
+            ctx.mark_non_differentiable(probs)
+            return y.view(B, L, d), probs
+        return (y.view(B, L, d),)
+
+    @staticmethod
+    def backward(ctx, dy, *unused):
+        B, L, d = ctx.shp
+        G = GradSink()
+        g = enc_layer_bwd(ctx.run, ctx.layer, ctx.saved, _f32c(dy).reshape(B * L, d).clone(), G)
+        ctx.saved = None
+        return (None, None, g.view(B, L, d), None, None) + G.collect(ctx.params)
+
+
+class DecLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, layer, run, x, e, src_mask_u8, trg_mask_u8, want_probs, *params):
+        x2, B, T, d = _flat3(x)
+        e2, _, Lk, _ = _flat3(e)
+        y, saved, p1, p2 = dec_layer_fwd(run, layer, x2, e2, B, T, Lk, src_mask_u8, trg_mask_u8,
+                                         want_probs)
+        ctx.layer, ctx.run, ctx.saved, ctx.params = layer, run, saved, params
+        ctx.shp = (B, T, Lk, d)
+        if want_probs:
+            ctx.mark_non_differentiable(p1, p2)
+            return y.view(B, T, d), p1, p2
+        return (y.view(B, T, d),)
+
+    @staticmethod
+    def backward(ctx, dy, *unused):
+        B, T, Lk, d = ctx.shp
+        G = GradSink()
+        de = torch.empty(B * Lk, d, dtype=torch.float32, device=dy.device)
+        g = dec_layer_bwd(ctx.run, ctx.layer, ctx.saved, _f32c(dy).reshape(B * T, d).clone(), de,
+                          True, G)
+        ctx.saved = None
+        return (None, None, g.view(B, T, d), de.view(B, Lk, d), None, None, None) + \
+            G.collect(ctx.params)

@@ -1,0 +1,94 @@
+"""Flat parameter / gradient storage for a whole model (HBM layout).
+
+All parameters live back to back (each 16-B aligned) in ONE fp32 buffer and all gradients in
+a second one, in named_parameters() order.  nn.Parameter objects keep their names and shapes
+(the checkpoint layout is untouched: state_dict() still yields the reference's keys) -- they
+are views into the flat buffer.  This is what makes the fused Adam a single launch, the
+data-parallel gradient exchange a handful of large RCCL calls over contiguous ranges, and
+lets the wgrad kernels write gradients in place (engine.GradSink).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+
+ALIGN = 4  # floats (16 B): float4 loads/stores in the Adam and reduction kernels
+
+
+class FlatModelMixin:
+    """Mixed into the top-level model classes.  Flattening happens automatically whenever
+    the module is moved to a CUDA device (`model.cuda()` in train1.py:102)."""
+
+    _gct_flat = None
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        first = next(self.parameters(), None)
+        if first is not None and first.is_cuda:
+            self.flatten_parameters()
+        else:
+            self._gct_flat = None
+            for p in self.parameters():
+                if hasattr(p, "_gct_gview"):
+                    del p._gct_gview
+        return out
+
+    def flatten_parameters(self):
+        params: List[nn.Parameter] = list(self.parameters())
+        if not params:
+            return
+        dev = params[0].device
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        pflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                v = pflat[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                p._gct_gview = gflat[o:o + p.numel()].view(p.shape)
+                if p.grad is not None:
+                    p._gct_gview.copy_(p.grad)
+                    p.grad = None
+        self._gct_flat = {"params": pflat, "grads": gflat, "offsets": offs, "order": params,
+                          "numel": total}
+
+    # -- helpers used by the fused optimiser and the data-parallel wrapper ------------------
+    def flat_params(self) -> torch.Tensor:
+        self._require_flat()
+        return self._gct_flat["params"]
+
+    def flat_grads(self) -> torch.Tensor:
+        self._require_flat()
+        return self._gct_flat["grads"]
+
+    def grads_are_flat(self) -> bool:
+        """True when every existing .grad aliases its slot of the flat gradient buffer."""
+        if self._gct_flat is None:
+            return False
+        for p in self._gct_flat["order"]:
+            if p.grad is not None and p.grad.data_ptr() != p._gct_gview.data_ptr():
+                return False
+        return True
+
+    def sync_grads_to_flat(self):
+        """Make the flat gradient buffer authoritative: copy stray .grad tensors in, zero the
+        slots of parameters that received no gradient this step (Vaetf's dead encoder.fc_*,
+        SURVEY 2.3) and point every .grad at its slot."""
+        self._require_flat()
+        for p in self._gct_flat["order"]:
+            if p.grad is None:
+                p._gct_gview.zero_()
+            elif p.grad.data_ptr() != p._gct_gview.data_ptr():
+                p._gct_gview.copy_(p.grad)
+                p.grad = p._gct_gview
+
+    def _require_flat(self):
+        if self._gct_flat is None:
+            raise RuntimeError("model parameters are not flattened: move the model to a ROCm "
+                               "device first (model.cuda())")

@@ -76,19 +76,25 @@ def norm_bwd(dy, x2d, alpha, mean, rstd, dalpha, dbias, dres=None, out=None, eps
 
 
 # ------------------------------------------------------------------------------ embedding
-def embed_pe_fwd(tok, table, cond, pe2d, n_c, scale, p, seed, site):
+def embed_pe_fwd(tok, table, cond, pe2d, n_c, scale, p, seed, site, d=None):
     _chk(tok, "embed.tok", torch.int64)
     B, S = tok.shape
-    vocab, d = table.shape
-    out = torch.empty(B * (S + n_c), d, dtype=torch.float32, device=table.device)
+    if table is not None:
+        vocab, d = table.shape
+    else:
+        vocab = 1
+    out = torch.empty(B * (S + n_c), d, dtype=torch.float32, device=pe2d.device)
     check(_L().gct_embed_pe_fwd(_p(tok), _p(table), _p(cond), _p(pe2d), _p(out), B, S, n_c, d, vocab,
                                 scale, p, seed, site, _st()), "gct_embed_pe_fwd")
     return out
 
 
-def embed_pe_bwd(dout, tok, dtable, dcond, n_c, scale, p, seed, site):
+def embed_pe_bwd(dout, tok, dtable, dcond, n_c, scale, p, seed, site, d=None):
     B, S = tok.shape
-    vocab, d = dtable.shape
+    if dtable is not None:
+        vocab, d = dtable.shape
+    else:
+        vocab = 1
     ws = workspace(_L().gct_embed_ws_bytes(B, S, d, vocab), dout.device)
     check(_L().gct_embed_pe_bwd(_p(dout), _p(tok), _p(dtable), _p(dcond), _p(ws), B, S, n_c, d, vocab,
                                 scale, p, seed, site, _st()), "gct_embed_pe_bwd")
