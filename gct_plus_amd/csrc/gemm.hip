@@ -28,11 +28,13 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int TILE_FLOATS = BM * BK;  // 4096 floats = 16 KB per operand tile
 
+// A segmented matrix is addressed as base + {0, d1, d2}[segment] + ...: ONE pointer plus integer
+// element offsets (computed on the host).  Selecting among integer offsets compiles to
+// v_cndmask; selecting among pointers made hipcc either reload the pointer from kernarg memory
+// in front of every tile load or build an LDS lookup table and fall back to flat_load.
 struct Seg3 {
-  const float* p[3];
-};
-struct Seg3W {
-  float* p[3];
+  const float* p0;
+  int64_t d1, d2;
 };
 
 struct GemmArgs {
@@ -43,14 +45,16 @@ struct GemmArgs {
   Seg3 b;
   int64_t ldb;
   int64_t b_nper;
-  Seg3W c;
+  float* c0;
+  int64_t c_d1, c_d2;
   int64_t ldc;
   int64_t c_nper;
   int64_t slab_stride;  // split-K: C written to c.p[0] + z*slab_stride
   int64_t ksplit;       // K range per split (multiple of BK), == K when no split
   int nsplit;
   int epi;              // fwd: GCT_EPI_* ; dgrad: 16 + GCT_DEPI_* ; slab: 32
-  Seg3 bias;
+  const float* bias0;  // nullptr: no bias
+  int64_t bias_d1, bias_d2;
   const float* resid;
   float* pre;
   const float* pre_in;
@@ -64,9 +68,9 @@ enum { EPI_SLAB = 32, EPI_D0 = 16 };
 __device__ __forceinline__ const float* seg_ptr(const Seg3& s, int64_t idx, int64_t nper,
                                                 int64_t& local) {
   // nseg <= 3: two compares instead of a 64-bit division
-  const int q = (int)(idx >= nper) + (int)(idx >= 2 * nper);
-  local = idx - q * nper;
-  return q == 0 ? s.p[0] : (q == 1 ? s.p[1] : s.p[2]);
+  const bool g1 = idx >= nper, g2 = idx >= 2 * nper;
+  local = idx - (g2 ? 2 * nper : (g1 ? nper : 0));
+  return s.p0 + (g2 ? s.d2 : (g1 ? s.d1 : 0));
 }
 
 // ---- global -> register tile loaders ------------------------------------------------
@@ -228,6 +232,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
   const int64_t kbeg = (int64_t)z * g.ksplit;
   const int64_t kend = (kbeg + g.ksplit < g.K) ? kbeg + g.ksplit : g.K;
 
+  const Seg3 sa = g.a, sb = g.b;
+
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -239,13 +245,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
   float4 ra[4], rb[4];
   auto gload = [&](int64_t k0) {
     if (A_KC)
-      load_kc<VEC, true>(ra, g.a, g.lda, g.a_nper, m0, g.M, k0, kend, tid);
+      load_kc<VEC, true>(ra, sa, g.lda, g.a_nper, m0, g.M, k0, kend, tid);
     else
-      load_rc<VEC, false>(ra, g.a, g.lda, g.a_nper, m0, g.M, k0, kend, tid);
+      load_rc<VEC, false>(ra, sa, g.lda, g.a_nper, m0, g.M, k0, kend, tid);
     if (B_KC)
-      load_kc<VEC, false>(rb, g.b, g.ldb, g.b_nper, n0, g.N, k0, kend, tid);
+      load_kc<VEC, false>(rb, sb, g.ldb, g.b_nper, n0, g.N, k0, kend, tid);
     else
-      load_rc<VEC, true>(rb, g.b, g.ldb, g.b_nper, n0, g.N, k0, kend, tid);
+      load_rc<VEC, true>(rb, sb, g.ldb, g.b_nper, n0, g.N, k0, kend, tid);
   };
   auto lstore = [&](int buf) {
     float* la = lds + buf * 2 * TILE_FLOATS;
@@ -292,16 +298,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
       float* cbase;
       float bias = 0.f;
       if (g.epi == EPI_SLAB) {
-        cbase = g.c.p[0] + (int64_t)z * g.slab_stride;
+        cbase = g.c0 + (int64_t)z * g.slab_stride;
         cloc = col;
       } else {
-        const int q = (int)(col >= g.c_nper) + (int)(col >= 2 * g.c_nper);
-        cloc = col - q * g.c_nper;
-        cbase = q == 0 ? g.c.p[0] : (q == 1 ? g.c.p[1] : g.c.p[2]);
-        if (g.epi < EPI_D0) {
-          const float* bp = q == 0 ? g.bias.p[0] : (q == 1 ? g.bias.p[1] : g.bias.p[2]);
-          if (bp) bias = bp[cloc];
-        }
+        const bool g1 = col >= g.c_nper, g2 = col >= 2 * g.c_nper;
+        cloc = col - (g2 ? 2 * g.c_nper : (g1 ? g.c_nper : 0));
+        cbase = g.c0 + (g2 ? g.c_d2 : (g1 ? g.c_d1 : 0));
+        if (g.epi < EPI_D0 && g.bias0)
+          bias = g.bias0[(g2 ? g.bias_d2 : (g1 ? g.bias_d1 : 0)) + cloc];
       }
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
@@ -369,6 +373,14 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st) {
 
 inline bool al16(const void* p) { return p == nullptr || gct_aligned16(p); }
 
+inline Seg3 mkseg(const float* p0, const float* p1, const float* p2) {
+  Seg3 r;
+  r.p0 = p0;
+  r.d1 = p1 ? (int64_t)(p1 - p0) : 0;
+  r.d2 = p2 ? (int64_t)(p2 - p0) : 0;
+  return r;
+}
+
 // deterministic slab reduction + bias-gradient helpers live in reduce.hip
 }  // namespace
 
@@ -410,11 +422,13 @@ extern "C" int gct_linear_fwd(const float* x, int64_t ldx, int64_t M, int K, con
   GCT_CHECK_ARG(p >= 0.f && p < 1.f, "linear_fwd: dropout p out of range");
   GemmArgs g = {};
   g.M = M; g.N = (int64_t)nseg * nper; g.K = K;
-  g.a.p[0] = x; g.a.p[1] = x; g.a.p[2] = x; g.lda = ldx; g.a_nper = INT64_MAX / 4;
-  g.b.p[0] = w0; g.b.p[1] = w1; g.b.p[2] = w2; g.ldb = ldw; g.b_nper = nper;
-  g.c.p[0] = y0; g.c.p[1] = y1; g.c.p[2] = y2; g.ldc = ldy; g.c_nper = nper;
+  GCT_CHECK_ARG(!b0 || nseg < 2 || b1, "linear_fwd: bias of segment 1 missing");
+  GCT_CHECK_ARG(!b0 || nseg < 3 || b2, "linear_fwd: bias of segment 2 missing");
+  g.a = mkseg(x, nullptr, nullptr); g.lda = ldx; g.a_nper = INT64_MAX / 4;
+  g.b = mkseg(w0, w1, w2); g.ldb = ldw; g.b_nper = nper;
+  g.c0 = y0; g.c_d1 = y1 ? y1 - y0 : 0; g.c_d2 = y2 ? y2 - y0 : 0; g.ldc = ldy; g.c_nper = nper;
   g.ksplit = K; g.nsplit = 1; g.epi = epi;
-  g.bias.p[0] = b0; g.bias.p[1] = b1; g.bias.p[2] = b2;
+  g.bias0 = b0; g.bias_d1 = (b0 && b1) ? b1 - b0 : 0; g.bias_d2 = (b0 && b2) ? b2 - b0 : 0;
   g.resid = resid; g.pre = pre;
   g.thr = gct_drop_threshold(p); g.keep_scale = 1.0f / (1.0f - p); g.rng = gct_rng_make(seed, site);
   const bool vec = al16(x) && al16(w0) && al16(w1) && al16(w2) && (ldx % 4 == 0) &&
@@ -435,9 +449,9 @@ extern "C" int gct_linear_dgrad(const float* dy0, const float* dy1, const float*
   GCT_CHECK_ARG(p >= 0.f && p < 1.f, "linear_dgrad: dropout p out of range");
   GemmArgs g = {};
   g.M = M; g.N = K; g.K = (int64_t)nseg * nper;  // reduce over the layer's output features
-  g.a.p[0] = dy0; g.a.p[1] = dy1; g.a.p[2] = dy2; g.lda = lddy; g.a_nper = nper;
-  g.b.p[0] = w0; g.b.p[1] = w1; g.b.p[2] = w2; g.ldb = ldw; g.b_nper = nper;
-  g.c.p[0] = dx; g.c.p[1] = dx; g.c.p[2] = dx; g.ldc = lddx; g.c_nper = INT64_MAX / 4;
+  g.a = mkseg(dy0, dy1, dy2); g.lda = lddy; g.a_nper = nper;
+  g.b = mkseg(w0, w1, w2); g.ldb = ldw; g.b_nper = nper;
+  g.c0 = dx; g.ldc = lddx; g.c_nper = INT64_MAX / 4;
   g.ksplit = g.K; g.nsplit = 1; g.epi = EPI_D0 + depi;
   g.pre_in = pre;
   g.thr = gct_drop_threshold(p); g.keep_scale = 1.0f / (1.0f - p); g.rng = gct_rng_make(seed, site);
@@ -464,9 +478,9 @@ extern "C" int gct_linear_wgrad(const float* dy0, const float* dy1, const float*
   const int splits = wgrad_splits(M, Ntot, K);
   GemmArgs g = {};
   g.M = Ntot; g.N = K; g.K = M;  // dW[n][k] = sum_m dY[m][n] X[m][k]
-  g.a.p[0] = dy0; g.a.p[1] = dy1; g.a.p[2] = dy2; g.lda = lddy; g.a_nper = nper;
-  g.b.p[0] = x; g.b.p[1] = x; g.b.p[2] = x; g.ldb = ldx; g.b_nper = INT64_MAX / 4;
-  g.c.p[0] = ws; g.ldc = K; g.c_nper = INT64_MAX / 4;
+  g.a = mkseg(dy0, dy1, dy2); g.lda = lddy; g.a_nper = nper;
+  g.b = mkseg(x, nullptr, nullptr); g.ldb = ldx; g.b_nper = INT64_MAX / 4;
+  g.c0 = ws; g.ldc = K; g.c_nper = INT64_MAX / 4;
   g.slab_stride = Ntot * K;
   int64_t ks = (M + splits - 1) / splits;
   ks = (ks + BK - 1) / BK * BK;

@@ -63,7 +63,9 @@ class GradSink:
         if t is None:
             v = getattr(p, "_gct_gview", None)
             if v is not None and (p.grad is None or p.grad.data_ptr() != v.data_ptr()):
-                t = v
+                # a FRESH view object: AccumulateGrad only adopts (instead of cloning) a
+                # gradient tensor nobody else holds a reference to
+                t = v.view(v.shape)
             else:
                 t = torch.empty_like(p)
             self.out[p] = t

@@ -101,6 +101,29 @@ def embed_pe_bwd(dout, tok, dtable, dcond, n_c, scale, p, seed, site, d=None):
 
 
 # --------------------------------------------------------------------------------- linear
+# Optional per-launch timing of the GEMM family (bench.py roofline leg): when PROFILE is a
+# dict, every gct_linear_* launch is bracketed by HIP events on the launch stream and logged as
+# (kernel kind, flops, start event, end event).  Off (None) in normal operation.
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, kind, flops):
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.setdefault(self.kind, []).append((self.flops, self.e0, self.e1))
+
+
 def _seg3(ts: Sequence[Optional[torch.Tensor]]):
     ts = list(ts) + [None] * (3 - len(ts))
     return [_p(t) for t in ts]
@@ -116,9 +139,10 @@ def linear_fwd(x2d, ws_: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Ten
     w = _seg3(ws_)
     b = _seg3(bs)
     y = _seg3(outs)
-    check(_L().gct_linear_fwd(_p(x2d), x2d.stride(0), M, K, w[0], w[1], w[2], ws_[0].stride(0),
-                              b[0], b[1], b[2], len(ws_), nper, y[0], y[1], y[2], ldy, epi,
-                              _p(resid), _p(pre), p, seed, site, _st()), "gct_linear_fwd")
+    with _Timed("gemm_fwd", 2.0 * M * K * nper * len(ws_)):
+        check(_L().gct_linear_fwd(_p(x2d), x2d.stride(0), M, K, w[0], w[1], w[2], ws_[0].stride(0),
+                                  b[0], b[1], b[2], len(ws_), nper, y[0], y[1], y[2], ldy, epi,
+                                  _p(resid), _p(pre), p, seed, site, _st()), "gct_linear_fwd")
 
 
 def linear_dgrad(dys: Sequence[torch.Tensor], lddy: int, M: int, ws_: Sequence[torch.Tensor], dx,
@@ -126,9 +150,10 @@ def linear_dgrad(dys: Sequence[torch.Tensor], lddy: int, M: int, ws_: Sequence[t
     nper, K = ws_[0].shape
     d = _seg3(dys)
     w = _seg3(ws_)
-    check(_L().gct_linear_dgrad(d[0], d[1], d[2], lddy, M, len(ws_), nper, w[0], w[1], w[2],
-                                ws_[0].stride(0), K, _p(dx), dx.stride(0), depi, _p(pre), p, seed,
-                                site, _st()), "gct_linear_dgrad")
+    with _Timed("gemm_dgrad", 2.0 * M * K * nper * len(ws_)):
+        check(_L().gct_linear_dgrad(d[0], d[1], d[2], lddy, M, len(ws_), nper, w[0], w[1], w[2],
+                                    ws_[0].stride(0), K, _p(dx), dx.stride(0), depi, _p(pre), p,
+                                    seed, site, _st()), "gct_linear_dgrad")
 
 
 def linear_wgrad(dys: Sequence[torch.Tensor], lddy: int, x2d, dws: Sequence[torch.Tensor],
@@ -140,9 +165,10 @@ def linear_wgrad(dys: Sequence[torch.Tensor], lddy: int, x2d, dws: Sequence[torc
     dw = _seg3(dws)
     db = _seg3(dbs)
     ws = workspace(_L().gct_wgrad_ws_bytes(M, nseg * nper, K), x2d.device)
-    check(_L().gct_linear_wgrad(d[0], d[1], d[2], lddy, M, nseg, nper, _p(x2d), x2d.stride(0), K,
-                                dw[0], dw[1], dw[2], K, db[0], db[1], db[2], _p(ws), _st()),
-          "gct_linear_wgrad")
+    with _Timed("gemm_wgrad+bias+reduce", 2.0 * M * K * nper * nseg):
+        check(_L().gct_linear_wgrad(d[0], d[1], d[2], lddy, M, nseg, nper, _p(x2d), x2d.stride(0),
+                                    K, dw[0], dw[1], dw[2], K, db[0], db[1], db[2], _p(ws), _st()),
+              "gct_linear_wgrad")
 
 
 def dropout_bwd(dout2d, p, seed, site, out=None):

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the hot kernels at the BASELINE shapes (B=512): per-shape time and
+TFLOP/s (GEMMs) or GB/s (bandwidth kernels), HIP-event timed, interleaved rounds."""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gct_plus_amd import ops  # noqa: E402
+
+
+def timeit(fn, reps=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def gemm_suite(reps, only=None):
+    dev = "cuda"
+    shapes = [("qkv", 40960, 512, 512, 3), ("out", 40960, 512, 512, 1), ("ffn1", 40960, 512, 2048, 1),
+              ("ffn2", 40960, 2048, 512, 1), ("kv", 40960, 512, 512, 2), ("mulv", 40960, 512, 128, 2),
+              ("sq4k", 4096, 4096, 4096, 1)]
+    for name, M, K, nper, nseg in shapes:
+        if only and name not in only:
+            continue
+        N = nper * nseg
+        x = torch.randn(M, K, device=dev)
+        ws = [torch.randn(nper, K, device=dev) * K ** -0.5 for _ in range(nseg)]
+        bs = [torch.randn(nper, device=dev) for _ in range(nseg)]
+        y = torch.empty(M, N, device=dev)
+        outs = [y[:, s * nper:] for s in range(nseg)]
+        dy = torch.randn(M, N, device=dev)
+        dys = [dy[:, s * nper:] for s in range(nseg)]
+        dx = torch.empty(M, K, device=dev)
+        dws = [torch.empty(nper, K, device=dev) for _ in range(nseg)]
+        dbs = [torch.empty(nper, device=dev) for _ in range(nseg)]
+        fl = 2.0 * M * K * N
+        for kind, fn in (("fwd", lambda: ops.linear_fwd(x, ws, bs, outs, N)),
+                         ("dgrad", lambda: ops.linear_dgrad(dys, N, M, ws, dx)),
+                         ("wgrad", lambda: ops.linear_wgrad(dys, N, x, dws, dbs))):
+            med, best = timeit(fn, reps)
+            print(f"gemm {name:5s} {kind:5s} M={M} K={K} N={N}: {med*1e6:8.1f} us  {fl/med/1e12:6.1f} TF  (best {fl/best/1e12:6.1f})",
+                  flush=True)
+
+
+def attn_suite(reps):
+    dev = "cuda"
+    for name, B, H, Lq, Lk, dk, causal in (("enc", 512, 8, 80, 80, 64, False), ("dec", 512, 8, 81, 81, 64, True),
+                                           ("cross", 512, 8, 81, 80, 64, False)):
+        d = H * dk
+        qkv = torch.randn(B * max(Lq, Lk), 3 * d, device=dev)
+        mask = torch.ones(B, Lq, Lk, dtype=torch.uint8, device=dev).tril_() if causal else \
+            torch.ones(B, Lk, dtype=torch.uint8, device=dev)
+        q, k, v = qkv, qkv[:, d:], qkv[:, 2 * d:]
+        o, lse, _ = ops.attn_fwd(q, k, v, 3 * d, 3 * d, 3 * d, mask, B, H, Lq, Lk, dk, 0.1, 1, 1)
+        do = torch.randn_like(o)
+        dqkv = torch.empty_like(qkv)
+        fl = 4.0 * B * H * Lq * Lk * dk
+        med, best = timeit(lambda: ops.attn_fwd(q, k, v, 3 * d, 3 * d, 3 * d, mask, B, H, Lq, Lk, dk, 0.1, 1, 1), reps)
+        print(f"attn {name:5s} fwd: {med*1e6:8.1f} us  {fl/med/1e12:6.2f} TF", flush=True)
+        med, best = timeit(lambda: ops.attn_bwd(q, k, v, 3 * d, 3 * d, 3 * d, mask, o, do, lse, dqkv, dqkv[:, d:],
+                                                dqkv[:, 2 * d:], 3 * d, 3 * d, 3 * d, B, H, Lq, Lk, dk, 0.1, 1, 1), reps)
+        print(f"attn {name:5s} bwd: {med*1e6:8.1f} us  {2.5*fl/med/1e12:6.2f} TF", flush=True)
+
+
+def bw_suite(reps):
+    dev = "cuda"
+    M, d = 40960, 512
+    x = torch.randn(M, d, device=dev)
+    a, b = torch.ones(d, device=dev), torch.zeros(d, device=dev)
+    y, mean, rstd = ops.norm_fwd(x, a, b)
+    med, _ = timeit(lambda: ops.norm_fwd(x, a, b, out=y), reps)
+    print(f"norm fwd: {med*1e6:7.1f} us {2*M*d*4/med/1e9:7.0f} GB/s", flush=True)
+    da, db = torch.empty(d, device=dev), torch.empty(d, device=dev)
+    dx = torch.empty_like(x)
+    med, _ = timeit(lambda: ops.norm_bwd(y, x, a, mean, rstd, da, db, dres=x, out=dx), reps)
+    print(f"norm bwd: {med*1e6:7.1f} us {4*M*d*4/med/1e9:7.0f} GB/s", flush=True)
+    n = 44_514_334
+    p, g, m, v = (torch.randn(n, device=dev) for _ in range(4))
+    v.abs_()
+    med, _ = timeit(lambda: ops.adam_step(p, g, m, v, 1e-4, 0.9, 0.98, 1e-9, 3), reps)
+    print(f"adam    : {med*1e6:7.1f} us {28*n/med/1e9:7.0f} GB/s", flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--suite", default="gemm,attn,bw")
+    ap.add_argument("--only", default="")
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    if "gemm" in a.suite:
+        gemm_suite(a.reps, a.only.split(",") if a.only else None)
+    if "attn" in a.suite:
+        attn_suite(a.reps)
+    if "bw" in a.suite:
+        bw_suite(a.reps)
