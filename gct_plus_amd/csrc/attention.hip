@@ -7,14 +7,21 @@
 // Machine mapping (gfx950): L <= 128 and dk <= 64, so a whole (batch, head) problem lives in one
 // workgroup's LDS: Q (pre-scaled), K, V [L][dk+4] fp32 plus one flag byte per (q,k) holding
 // {in-range, not-masked, dropout-keep}.  All products run on v_mfma_f32_16x16x4_f32 (exact fp32).
-// The score tile is computed TRANSPOSED (S^T = K Q^T): its accumulator layout then has the key
-// index on the registers and the query on the lane, which is exactly the B-operand layout the
-// following P.V product (summing over keys) needs -- probabilities never leave registers and
-// never touch HBM; a softmax row is reduced over 4 regs x tiles in-lane plus two shuffles.
-// Backward recomputes probabilities from the saved log-sum-exp (no [B,H,L,L] tensor is stored):
-//   pass A (query-tile owners):  S^T, dP^T -> dS^T -> dQ
-//   pass B (key-tile owners)  :  S, dP -> P_drop, dS -> dV, dK   (sums over the register index)
-// Roofline: HBM-bound on q,k,v,o (+ their gradients); 4.L.d flop/token ~ 3 % of the step.
+//  * The score tile is computed TRANSPOSED (S^T = K Q^T): its accumulator layout has the key
+//    index on the registers and the query on the lane -- exactly the B-operand layout of the
+//    following P.V product (which sums over keys).  Probabilities never leave registers and
+//    never touch HBM; a softmax row is reduced over 4 regs x tiles in-lane plus two shuffles.
+//  * 16x16 score tiles whose mask bytes are all zero (above the causal diagonal, beyond a
+//    sample's length) are skipped -- decided from the staged flags, wave-uniform, and only
+//    when every query row of the tile has at least one visible key, so the masked_fill(-1e9)
+//    semantics (uniform row when everything is masked) stay exact.
+//  * staging loads are issued in batches (fully unrolled, loads before LDS stores) and the
+//    workgroup is 8 (fwd) / 12 (bwd) waves so HBM/L2 latency overlaps the MFMA phases.
+//  * Backward recomputes probabilities from the saved log-sum-exp (no [B,H,L,L] tensor):
+//      pass A (one wave per query tile):  S^T, dP^T -> dS^T -> dQ
+//      pass B (one wave per key tile)  :  S, dP -> P_drop, dS -> dV, dK
+//    both passes only read LDS, so they run CONCURRENTLY on different waves of the workgroup.
+// Roofline: HBM-bound on q,k,v,o (+ gradients); 4.L.d flop/token ~ 3 % of the step's flops.
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -22,6 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int NT_MAX = 8;  // L <= 128
+constexpr int FWD_THREADS = 512, BWD_THREADS = 768;
 
 struct AttnArgs {
   const float *q, *k, *v;
@@ -46,27 +54,59 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// stage rows [0,L) of a [B][L][ld] head slice into LDS [LP][SD], zero padded, optional scale
-template <int DK>
+// stage rows [0,L) of a [B][L][ld] head slice into LDS [LP][SD], zero padded, optional scale.
+// Fully unrolled: all global loads of a thread are in flight before the first LDS store.
+template <int DK, int NTHR>
 __device__ __forceinline__ void stage(float* dst, const float* src, int64_t ld, int b, int h, int L,
                                       int LP, float scale, int tid) {
   constexpr int SD = DK + 4, C = DK / 4;
-  for (int idx = tid; idx < LP * C; idx += 256) {
+  constexpr int ITERS = (16 * NT_MAX * C + NTHR - 1) / NTHR;
+  float4 v[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = tid + it * NTHR;
     const int r = idx / C, c = idx - r * C;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < L) {
-      v = *reinterpret_cast<const float4*>(src + ((int64_t)b * L + r) * ld + h * DK + c * 4);
-      v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+    v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < L) v[it] = *reinterpret_cast<const float4*>(src + ((int64_t)b * L + r) * ld + h * DK + c * 4);
+  }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = tid + it * NTHR;
+    const int r = idx / C, c = idx - r * C;
+    if (r < LP) {
+      float4 w = v[it];
+      w.x *= scale; w.y *= scale; w.z *= scale; w.w *= scale;
+      *reinterpret_cast<float4*>(dst + r * SD + c * 4) = w;
     }
-    *reinterpret_cast<float4*>(dst + r * SD + c * 4) = v;
   }
 }
 
 // flags[q][k]: bit2 in range, bit0 not masked, bit1 dropout keep. One Philox call per (q, 4 keys).
+template <int NTHR>
 __device__ __forceinline__ void build_flags(uint32_t* flags32, const AttnArgs& a, int b, int h,
                                             int LQP, int LKP, int tid) {
   const int KG = LKP / 4;
-  for (int idx = tid; idx < LQP * KG; idx += 256) {
+  constexpr int ITERS = (16 * NT_MAX * 4 * NT_MAX + NTHR - 1) / NTHR;
+  uint32_t mv[ITERS];
+  // pass 1: all mask bytes in flight (4 consecutive bytes per item, packed into one word)
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = tid + it * NTHR;
+    const int q = idx / KG, kg = idx - q * KG;
+    uint32_t w = 0x01010101u;
+    if (a.mask && q < a.Lq && idx < LQP * KG) {
+      const uint8_t* mp = a.mask + (int64_t)b * a.mask_sb + (int64_t)q * a.mask_sq + kg * 4;
+      w = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (kg * 4 + e < a.Lk) w |= (mp[e] ? 1u : 0u) << (8 * e);
+    }
+    mv[it] = w;
+  }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = tid + it * NTHR;
+    if (idx >= LQP * KG) continue;
     const int q = idx / KG, kg = idx - q * KG;
     uint32_t w = 0;
     if (q < a.Lq) {
@@ -76,19 +116,46 @@ __device__ __forceinline__ void build_flags(uint32_t* flags32, const AttnArgs& a
                           0xA4093822u, 0x299F31D0u);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int k = kg * 4 + e;
-        uint32_t f = 0;
-        if (k < a.Lk) {
-          f = 4u;
-          const uint8_t mv = a.mask ? a.mask[(int64_t)b * a.mask_sb + (int64_t)q * a.mask_sq + k] : 1;
-          if (mv) f |= 1u;
+        if (kg * 4 + e < a.Lk) {
+          uint32_t f = 4u | ((mv[it] >> (8 * e)) & 1u);
           if (gct_pick(bits, e) >= a.thr) f |= 2u;
+          w |= f << (8 * e);
         }
-        w |= f << (8 * e);
       }
     }
     flags32[idx] = w;
   }
+}
+
+// rowok[q] = row q has at least one visible key (or is a padding row);
+// tile_any[u*NT_MAX+t] = tile (u,t) has at least one visible (q,k).  Needs a barrier after.
+template <int NTHR>
+__device__ __forceinline__ void build_tile_maps(const uint32_t* flags32, uint8_t* rowok,
+                                                uint8_t* tile_any, int Lq, int LQP, int LKP, int tid) {
+  const int KG = LKP / 4, nkt = LKP / 16, nqt = LQP / 16;
+  for (int q = tid; q < LQP; q += NTHR) {
+    uint32_t any = 0;
+    for (int kg = 0; kg < KG; ++kg) any |= flags32[q * KG + kg] & 0x01010101u;
+    rowok[q] = (q >= Lq) || any != 0;
+  }
+  for (int ti = tid; ti < nqt * nkt; ti += NTHR) {
+    const int u = ti / nkt, t = ti - u * nkt;
+    uint32_t any = 0;
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) any |= flags32[(16 * u + r) * KG + 4 * t + j] & 0x01010101u;
+    tile_any[u * NT_MAX + t] = any != 0;
+  }
+}
+
+// bit t set => key tile t must be computed for query tile u
+__device__ __forceinline__ uint32_t tiles_for_q(const uint8_t* rowok, const uint8_t* tile_any, int u,
+                                                int nkt, int c16) {
+  const bool ok = __all(rowok[16 * u + c16] != 0);
+  uint32_t use = 0;
+  for (int t = 0; t < nkt; ++t)
+    if (!ok || tile_any[u * NT_MAX + t]) use |= 1u << t;
+  return __builtin_amdgcn_readfirstlane(use);
 }
 
 __device__ __forceinline__ float score_of(float s, uint32_t f) {
@@ -97,8 +164,8 @@ __device__ __forceinline__ float score_of(float s, uint32_t f) {
 
 // ------------------------------------------------------------------------------ forward
 template <int NDT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
-  constexpr int DK = 16 * NDT, SD = DK + 4;
+__global__ __launch_bounds__(FWD_THREADS) void attn_fwd_kernel(const AttnArgs a) {
+  constexpr int DK = 16 * NDT, SD = DK + 4, NW = FWD_THREADS / 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
@@ -107,30 +174,36 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   float* Ks = Qs + LQP * SD;
   float* Vs = Ks + LKP * SD;
   uint32_t* flags32 = reinterpret_cast<uint32_t*>(Vs + LKP * SD);
-  stage<DK>(Qs, a.q, a.ldq, b, h, a.Lq, LQP, a.scale, tid);
-  stage<DK>(Ks, a.k, a.ldk, b, h, a.Lk, LKP, 1.0f, tid);
-  stage<DK>(Vs, a.v, a.ldv, b, h, a.Lk, LKP, 1.0f, tid);
-  build_flags(flags32, a, b, h, LQP, LKP, tid);
+  uint8_t* rowok = reinterpret_cast<uint8_t*>(flags32 + LQP * KG);
+  uint8_t* tile_any = rowok + 16 * NT_MAX;
+  stage<DK, FWD_THREADS>(Qs, a.q, a.ldq, b, h, a.Lq, LQP, a.scale, tid);
+  stage<DK, FWD_THREADS>(Ks, a.k, a.ldk, b, h, a.Lk, LKP, 1.0f, tid);
+  stage<DK, FWD_THREADS>(Vs, a.v, a.ldv, b, h, a.Lk, LKP, 1.0f, tid);
+  build_flags<FWD_THREADS>(flags32, a, b, h, LQP, LKP, tid);
+  __syncthreads();
+  build_tile_maps<FWD_THREADS>(flags32, rowok, tile_any, a.Lq, LQP, LKP, tid);
   __syncthreads();
 
-  for (int u = wave; u < LQP / 16; u += 4) {
+  for (int u = wave; u < LQP / 16; u += NW) {
     const int q = 16 * u + c16;
+    const uint32_t use = tiles_for_q(rowok, tile_any, u, nkt, c16);
     f32x4 sacc[NT_MAX];
 #pragma unroll
     for (int t = 0; t < NT_MAX; ++t) sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // S^T[k][q] = sum_d K[k][d] * Qs[q][d]
-#pragma unroll 2
+#pragma unroll 4
     for (int s = 0; s < DK / 4; ++s) {
       const float bq = Qs[q * SD + 4 * s + g];
 #pragma unroll
       for (int t = 0; t < NT_MAX; ++t)
-        if (t < nkt) sacc[t] = mfma16(Ks[(16 * t + c16) * SD + 4 * s + g], bq, sacc[t]);
+        if ((use >> t) & 1u) sacc[t] = mfma16(Ks[(16 * t + c16) * SD + 4 * s + g], bq, sacc[t]);
     }
     // mask + softmax over keys (regs x tiles in-lane, then lanes l^16, l^32)
     uint32_t fw[NT_MAX];
     float m = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < NT_MAX; ++t)
+    for (int t = 0; t < NT_MAX; ++t) {
+      fw[t] = 0;
       if (t < nkt) {
         fw[t] = flags32[q * KG + 4 * t + g];
 #pragma unroll
@@ -140,6 +213,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
           m = fmaxf(m, sv);
         }
       }
+    }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     if (m == -INFINITY) m = 0.f;
@@ -176,7 +250,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     for (int dt = 0; dt < NDT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT_MAX; ++t)
-      if (t < nkt) {
+      if ((use >> t) & 1u) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float bp = sacc[t][r];
@@ -197,8 +271,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 
 // ----------------------------------------------------------------------------- backward
 template <int NDT>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
-  constexpr int DK = 16 * NDT, SD = DK + 4;
+__global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a) {
+  constexpr int DK = 16 * NDT, SD = DK + 4, NW = BWD_THREADS / 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
@@ -212,13 +286,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
   float* del_s = lse_s + LQP;     // [LQP]
   uint32_t* flags32 = reinterpret_cast<uint32_t*>(del_s + LQP);
   const uint8_t* flags8 = reinterpret_cast<const uint8_t*>(flags32);
-  stage<DK>(Qs, a.q, a.ldq, b, h, a.Lq, LQP, a.scale, tid);
-  stage<DK>(Ks, a.k, a.ldk, b, h, a.Lk, LKP, 1.0f, tid);
-  stage<DK>(Vs, a.v, a.ldv, b, h, a.Lk, LKP, 1.0f, tid);
-  stage<DK>(dOs, a.dout, a.ldo, b, h, a.Lq, LQP, 1.0f, tid);
-  build_flags(flags32, a, b, h, LQP, LKP, tid);
+  uint8_t* rowok = reinterpret_cast<uint8_t*>(flags32 + LQP * KG);
+  uint8_t* tile_any = rowok + 16 * NT_MAX;
+  stage<DK, BWD_THREADS>(Qs, a.q, a.ldq, b, h, a.Lq, LQP, a.scale, tid);
+  stage<DK, BWD_THREADS>(Ks, a.k, a.ldk, b, h, a.Lk, LKP, 1.0f, tid);
+  stage<DK, BWD_THREADS>(Vs, a.v, a.ldv, b, h, a.Lk, LKP, 1.0f, tid);
+  stage<DK, BWD_THREADS>(dOs, a.dout, a.ldo, b, h, a.Lq, LQP, 1.0f, tid);
+  build_flags<BWD_THREADS>(flags32, a, b, h, LQP, LKP, tid);
   // delta[q] = sum_d dO[q][d] * O[q][d]  (16 lanes per row)
-  for (int r0 = tid >> 4; r0 < LQP; r0 += 16) {
+  for (int r0 = tid >> 4; r0 < LQP; r0 += BWD_THREADS / 16) {
     float acc = 0.f;
     if (r0 < a.Lq) {
       const float* orow = a.o_in + ((int64_t)b * a.Lq + r0) * a.ldo + h * DK;
@@ -239,111 +315,117 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
     }
   }
   __syncthreads();
+  build_tile_maps<BWD_THREADS>(flags32, rowok, tile_any, a.Lq, LQP, LKP, tid);
+  __syncthreads();
 
-  // ---- pass A: dQ. Wave owns query tile u; key index on registers.
-  for (int u = wave; u < nqt; u += 4) {
-    const int q = 16 * u + c16;
-    f32x4 sacc[NT_MAX], pacc[NT_MAX];
+  // work units 0..nqt-1 = pass A (query tiles), nqt..nqt+nkt-1 = pass B (key tiles)
+  for (int unit = wave; unit < nqt + nkt; unit += NW) {
+    if (unit < nqt) {
+      // ---- pass A: dQ for query tile u; key index on registers.
+      const int u = unit, q = 16 * u + c16;
+      const uint32_t use = tiles_for_q(rowok, tile_any, u, nkt, c16);
+      f32x4 sacc[NT_MAX], pacc[NT_MAX];
 #pragma unroll
-    for (int t = 0; t < NT_MAX; ++t) {
-      sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      pacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+      for (int t = 0; t < NT_MAX; ++t) {
+        sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        pacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll 2
-    for (int s = 0; s < DK / 4; ++s) {
-      const float bq = Qs[q * SD + 4 * s + g];
-      const float bd = dOs[q * SD + 4 * s + g];
+      for (int s = 0; s < DK / 4; ++s) {
+        const float bq = Qs[q * SD + 4 * s + g];
+        const float bd = dOs[q * SD + 4 * s + g];
+#pragma unroll
+        for (int t = 0; t < NT_MAX; ++t)
+          if ((use >> t) & 1u) {
+            sacc[t] = mfma16(Ks[(16 * t + c16) * SD + 4 * s + g], bq, sacc[t]);  // S^T
+            pacc[t] = mfma16(Vs[(16 * t + c16) * SD + 4 * s + g], bd, pacc[t]);  // dP^T
+          }
+      }
+      const float lse = lse_s[q], del = del_s[q];
 #pragma unroll
       for (int t = 0; t < NT_MAX; ++t)
-        if (t < nkt) {
-          sacc[t] = mfma16(Ks[(16 * t + c16) * SD + 4 * s + g], bq, sacc[t]);  // S^T
-          pacc[t] = mfma16(Vs[(16 * t + c16) * SD + 4 * s + g], bd, pacc[t]);  // dP^T
+        if ((use >> t) & 1u) {
+          const uint32_t w = flags32[q * KG + 4 * t + g];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t f = (w >> (8 * r)) & 0xffu;
+            const float p = (f & 4u) ? expf(score_of(sacc[t][r], f) - lse) : 0.f;
+            const float dpd = (f & 2u) ? pacc[t][r] * a.keep_scale : 0.f;
+            sacc[t][r] = (f & 1u) ? p * (dpd - del) : 0.f;  // dS^T (masked_fill passes no grad)
+          }
         }
-    }
-    const float lse = lse_s[q], del = del_s[q];
+      f32x4 qacc[NDT];
 #pragma unroll
-    for (int t = 0; t < NT_MAX; ++t)
-      if (t < nkt) {
-        const uint32_t w = flags32[q * KG + 4 * t + g];
+      for (int dt = 0; dt < NDT; ++dt) qacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const uint32_t f = (w >> (8 * r)) & 0xffu;
-          const float p = (f & 4u) ? expf(score_of(sacc[t][r], f) - lse) : 0.f;
-          const float dpd = (f & 2u) ? pacc[t][r] * a.keep_scale : 0.f;
-          sacc[t][r] = (f & 1u) ? p * (dpd - del) : 0.f;  // dS^T (masked_fill passes no grad)
+      for (int t = 0; t < NT_MAX; ++t)
+        if ((use >> t) & 1u) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float bs = sacc[t][r];
+            const float* krow = Ks + (16 * t + 4 * g + r) * SD + c16;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) qacc[dt] = mfma16(krow[16 * dt], bs, qacc[dt]);
+          }
         }
+      if (q < a.Lq) {
+        float* drow = a.dq + ((int64_t)b * a.Lq + q) * a.lddq + h * DK + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+          *reinterpret_cast<float4*>(drow + 16 * dt) =
+              make_float4(qacc[dt][0] * a.scale, qacc[dt][1] * a.scale, qacc[dt][2] * a.scale,
+                          qacc[dt][3] * a.scale);
       }
-    f32x4 qacc[NDT];
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) qacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < NT_MAX; ++t)
-      if (t < nkt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float bs = sacc[t][r];
-          const float* krow = Ks + (16 * t + 4 * g + r) * SD + c16;
-#pragma unroll
-          for (int dt = 0; dt < NDT; ++dt) qacc[dt] = mfma16(krow[16 * dt], bs, qacc[dt]);
-        }
-      }
-    if (q < a.Lq) {
-      float* drow = a.dq + ((int64_t)b * a.Lq + q) * a.lddq + h * DK + 4 * g;
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt)
-        *reinterpret_cast<float4*>(drow + 16 * dt) =
-            make_float4(qacc[dt][0] * a.scale, qacc[dt][1] * a.scale, qacc[dt][2] * a.scale,
-                        qacc[dt][3] * a.scale);
-    }
-  }
-
-  // ---- pass B: dK, dV. Wave owns key tile t; query index on registers.
-  for (int t = wave; t < nkt; t += 4) {
-    const int k = 16 * t + c16;
-    f32x4 vacc[NDT], kacc[NDT];
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-      vacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      kacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll 1
-    for (int u = 0; u < nqt; ++u) {
-      f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, pa = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int s = 0; s < DK / 4; ++s) {
-        sa = mfma16(Qs[(16 * u + c16) * SD + 4 * s + g], Ks[k * SD + 4 * s + g], sa);   // S[q][k]
-        pa = mfma16(dOs[(16 * u + c16) * SD + 4 * s + g], Vs[k * SD + 4 * s + g], pa);  // dP[q][k]
-      }
-      float pd[4], ds[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qq = 16 * u + 4 * g + r;
-        const uint32_t f = flags8[qq * LKP + k];
-        const float p = (f & 4u) ? expf(score_of(sa[r], f) - lse_s[qq]) : 0.f;
-        const float dpd = (f & 2u) ? pa[r] * a.keep_scale : 0.f;
-        pd[r] = (f & 2u) ? p * a.keep_scale : 0.f;
-        ds[r] = (f & 1u) ? p * (dpd - del_s[qq]) : 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float* dorow = dOs + (16 * u + 4 * g + r) * SD + c16;
-        const float* qrow = Qs + (16 * u + 4 * g + r) * SD + c16;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-          vacc[dt] = mfma16(dorow[16 * dt], pd[r], vacc[dt]);  // dV^T[d][k] += dO[q][d] Pd[q][k]
-          kacc[dt] = mfma16(qrow[16 * dt], ds[r], kacc[dt]);   // dK^T[d][k] += Qs[q][d] dS[q][k]
-        }
-      }
-    }
-    if (k < a.Lk) {
-      float* vrow = a.dv + ((int64_t)b * a.Lk + k) * a.lddv + h * DK + 4 * g;
-      float* krow = a.dk + ((int64_t)b * a.Lk + k) * a.lddk + h * DK + 4 * g;
+    } else {
+      // ---- pass B: dK, dV for key tile t; query index on registers.
+      const int t = unit - nqt, k = 16 * t + c16;
+      f32x4 vacc[NDT], kacc[NDT];
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        *reinterpret_cast<float4*>(vrow + 16 * dt) =
-            make_float4(vacc[dt][0], vacc[dt][1], vacc[dt][2], vacc[dt][3]);
-        *reinterpret_cast<float4*>(krow + 16 * dt) =
-            make_float4(kacc[dt][0], kacc[dt][1], kacc[dt][2], kacc[dt][3]);
+        vacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        kacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll 1
+      for (int u = 0; u < nqt; ++u) {
+        const bool ok = __all(rowok[16 * u + c16] != 0);
+        if (ok && !tile_any[u * NT_MAX + t]) continue;  // fully masked tile: P = dS = 0
+        f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, pa = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int s = 0; s < DK / 4; ++s) {
+          sa = mfma16(Qs[(16 * u + c16) * SD + 4 * s + g], Ks[k * SD + 4 * s + g], sa);   // S[q][k]
+          pa = mfma16(dOs[(16 * u + c16) * SD + 4 * s + g], Vs[k * SD + 4 * s + g], pa);  // dP[q][k]
+        }
+        float pd[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qq = 16 * u + 4 * g + r;
+          const uint32_t f = flags8[qq * LKP + k];
+          const float p = (f & 4u) ? expf(score_of(sa[r], f) - lse_s[qq]) : 0.f;
+          const float dpd = (f & 2u) ? pa[r] * a.keep_scale : 0.f;
+          pd[r] = (f & 2u) ? p * a.keep_scale : 0.f;
+          ds[r] = (f & 1u) ? p * (dpd - del_s[qq]) : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* dorow = dOs + (16 * u + 4 * g + r) * SD + c16;
+          const float* qrow = Qs + (16 * u + 4 * g + r) * SD + c16;
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) {
+            vacc[dt] = mfma16(dorow[16 * dt], pd[r], vacc[dt]);  // dV^T[d][k] += dO[q][d] Pd[q][k]
+            kacc[dt] = mfma16(qrow[16 * dt], ds[r], kacc[dt]);   // dK^T[d][k] += Qs[q][d] dS[q][k]
+          }
+        }
+      }
+      if (k < a.Lk) {
+        float* vrow = a.dv + ((int64_t)b * a.Lk + k) * a.lddv + h * DK + 4 * g;
+        float* krow = a.dk + ((int64_t)b * a.Lk + k) * a.lddk + h * DK + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          *reinterpret_cast<float4*>(vrow + 16 * dt) =
+              make_float4(vacc[dt][0], vacc[dt][1], vacc[dt][2], vacc[dt][3]);
+          *reinterpret_cast<float4*>(krow + 16 * dt) =
+              make_float4(kacc[dt][0], kacc[dt][1], kacc[dt][2], kacc[dt][3]);
+        }
       }
     }
   }
@@ -375,6 +457,8 @@ int check_common(const char* who, const float* q, int64_t ldq, const float* k, i
   return GCT_OK;
 }
 
+constexpr size_t MAPS_BYTES = 16 * NT_MAX + NT_MAX * NT_MAX;  // rowok + tile_any
+
 }  // namespace
 
 extern "C" int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk,
@@ -393,8 +477,8 @@ extern "C" int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
   a.thr = gct_drop_threshold(p); a.keep_scale = 1.0f / (1.0f - p); a.rng = gct_rng_make(seed, site);
   const int LQP = (Lq + 15) & ~15, LKP = (Lk + 15) & ~15, SD = dk + 4;
-  const size_t lds = (size_t)(LQP + 2 * LKP) * SD * 4 + (size_t)LQP * LKP;
-  dim3 grid((unsigned)(B * H)), block(256);
+  const size_t lds = (size_t)(LQP + 2 * LKP) * SD * 4 + (size_t)LQP * LKP + MAPS_BYTES;
+  dim3 grid((unsigned)(B * H)), block(FWD_THREADS);
   hipStream_t st = (hipStream_t)stream;
   static bool f4 = false, f2 = false, f1 = false;
   GCT_CHECK_ARG(lds <= 160 * 1024, "attn_fwd: needs %zu B of LDS", lds);
@@ -429,8 +513,9 @@ extern "C" int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
   a.thr = gct_drop_threshold(p); a.keep_scale = 1.0f / (1.0f - p); a.rng = gct_rng_make(seed, site);
   const int LQP = (Lq + 15) & ~15, LKP = (Lk + 15) & ~15, SD = dk + 4;
-  const size_t lds = (size_t)(2 * LQP + 2 * LKP) * SD * 4 + (size_t)LQP * 8 + (size_t)LQP * LKP;
-  dim3 grid((unsigned)(B * H)), block(256);
+  const size_t lds = (size_t)(2 * LQP + 2 * LKP) * SD * 4 + (size_t)LQP * 8 + (size_t)LQP * LKP +
+                     MAPS_BYTES;
+  dim3 grid((unsigned)(B * H)), block(BWD_THREADS);
   hipStream_t st = (hipStream_t)stream;
   static bool f4 = false, f2 = false, f1 = false;
   GCT_CHECK_ARG(lds <= 160 * 1024, "attn_bwd: needs %zu B of LDS", lds);

@@ -392,7 +392,8 @@ int64_t gct_colsum_ws_floats(int64_t M, int64_t N);
 
 static int wgrad_splits(int64_t M, int64_t Ntot, int64_t K) {
   const int64_t tiles = ((Ntot + BM - 1) / BM) * ((K + BN - 1) / BN);
-  int64_t want = (1024 + tiles - 1) / tiles;  // ~4 blocks per CU
+  // exactly one resident round: 256 CUs x 2 blocks (64 KB LDS each) = 512 blocks, never 513
+  int64_t want = 512 / tiles;
   const int64_t maxs = (M + 4 * BK - 1) / (4 * BK);
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;

@@ -6,27 +6,75 @@
 
 namespace {
 
+// dst[e] = sum_s slabs[s][e].  Block = CW float4-columns x SL slab-lanes (CW*SL = 256): lane sl
+// sums slabs sl, sl+SL, ... (4 independent loads in flight), the SL partials are combined
+// through LDS in fixed order => deterministic.  SL is picked from n so that even a 2 KB
+// destination (norm / bias partials, up to 1024 slabs) is reduced by many lanes in parallel.
+template <int SL>
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs,
                                                            int nslab, int64_t stride, float* d0,
                                                            float* d1, float* d2, int64_t nper,
                                                            int64_t n4, int accumulate) {
-  // n4 = number of float4 groups; nper (elements, multiple of 4) selects the destination
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t e = i * 4;
-    float4 a = *reinterpret_cast<const float4*>(slabs + e);
-    for (int s = 1; s < nslab; ++s) {
-      const float4 b = *reinterpret_cast<const float4*>(slabs + (int64_t)s * stride + e);
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  constexpr int CW = 256 / SL;
+  __shared__ float4 red[256];
+  const int c = threadIdx.x % CW, sl = threadIdx.x / CW;
+  for (int64_t base = (int64_t)blockIdx.x * CW; base < n4; base += (int64_t)gridDim.x * CW) {
+    const int64_t i = base + c;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+      const float* src = slabs + i * 4;
+      int s = sl;
+      for (; s + 3 * SL < nslab; s += 4 * SL) {
+        const float4 v0 = *reinterpret_cast<const float4*>(src + (int64_t)s * stride);
+        const float4 v1 = *reinterpret_cast<const float4*>(src + (int64_t)(s + SL) * stride);
+        const float4 v2 = *reinterpret_cast<const float4*>(src + (int64_t)(s + 2 * SL) * stride);
+        const float4 v3 = *reinterpret_cast<const float4*>(src + (int64_t)(s + 3 * SL) * stride);
+        a.x += (v0.x + v1.x) + (v2.x + v3.x);
+        a.y += (v0.y + v1.y) + (v2.y + v3.y);
+        a.z += (v0.z + v1.z) + (v2.z + v3.z);
+        a.w += (v0.w + v1.w) + (v2.w + v3.w);
+      }
+      for (; s < nslab; s += SL) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)s * stride);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
     }
-    const int q = (int)(e >= nper) + (int)(e >= 2 * nper);
-    float* d = (q == 0 ? d0 : (q == 1 ? d1 : d2)) + (e - q * nper);
-    if (accumulate) {
-      const float4 o = *reinterpret_cast<const float4*>(d);
-      a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+    __syncthreads();
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (sl == 0 && i < n4) {
+      for (int k = 1; k < SL; ++k) {
+        const float4 v = red[k * CW + c];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+      const int64_t e = i * 4;
+      const bool g1 = e >= nper, g2 = e >= 2 * nper;
+      float* d = (g2 ? d2 : (g1 ? d1 : d0)) + (e - (g2 ? 2 * nper : (g1 ? nper : 0)));
+      if (accumulate) {
+        const float4 o = *reinterpret_cast<const float4*>(d);
+        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+      }
+      *reinterpret_cast<float4*>(d) = a;
     }
-    *reinterpret_cast<float4*>(d) = a;
   }
+}
+
+static int launch_reduce(const float* slabs, int nslab, int64_t stride, float* d0, float* d1,
+                         float* d2, int64_t nper, int64_t n4, int accumulate, hipStream_t st) {
+  auto grid = [&](int cw) {
+    int64_t g = (n4 + cw - 1) / cw;
+    return dim3((unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g)));
+  };
+  if (n4 >= 16384 || nslab <= 4)
+    hipLaunchKernelGGL(reduce_slabs_kernel<4>, grid(64), dim3(256), 0, st, slabs, nslab, stride, d0,
+                       d1, d2, nper, n4, accumulate);
+  else if (n4 >= 1024 || nslab <= 16)
+    hipLaunchKernelGGL(reduce_slabs_kernel<16>, grid(16), dim3(256), 0, st, slabs, nslab, stride,
+                       d0, d1, d2, nper, n4, accumulate);
+  else
+    hipLaunchKernelGGL(reduce_slabs_kernel<64>, grid(4), dim3(256), 0, st, slabs, nslab, stride, d0,
+                       d1, d2, nper, n4, accumulate);
+  return 0;
 }
 
 __global__ __launch_bounds__(256) void reduce_slabs_scalar_kernel(const float* __restrict__ slabs,
@@ -136,8 +184,7 @@ int gct_reduce_slabs_seg(const float* slabs, int nslab, int64_t stride, float* d
                    gct_aligned16(slabs) && gct_aligned16(d0) && (!d1 || gct_aligned16(d1)) &&
                    (!d2 || gct_aligned16(d2));
   if (vec)
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, slabs, nslab,
-                       stride, d0, d1, d2, nper_elems, n / 4, 0);
+    launch_reduce(slabs, nslab, stride, d0, d1, d2, nper_elems, n / 4, 0, st);
   else
     hipLaunchKernelGGL(reduce_slabs_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, st, slabs,
                        nslab, stride, d0, d1, d2, nper_elems, n, 0);
@@ -178,8 +225,7 @@ extern "C" int gct_reduce_slabs(const float* slabs, int nslab, int64_t stride, f
   const int64_t big = INT64_MAX / 4;
   const bool vec = (n % 4 == 0) && (stride % 4 == 0) && gct_aligned16(slabs) && gct_aligned16(dst);
   if (vec)
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, slabs, nslab,
-                       stride, dst, dst, dst, big, n / 4, accumulate);
+    launch_reduce(slabs, nslab, stride, dst, dst, dst, big, n / 4, accumulate, st);
   else
     hipLaunchKernelGGL(reduce_slabs_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, st, slabs,
                        nslab, stride, dst, dst, dst, big, n, accumulate);

@@ -62,8 +62,14 @@ def attn_suite(reps):
                                            ("cross", 512, 8, 81, 80, 64, False)):
         d = H * dk
         qkv = torch.randn(B * max(Lq, Lk), 3 * d, device=dev)
-        mask = torch.ones(B, Lq, Lk, dtype=torch.uint8, device=dev).tril_() if causal else \
-            torch.ones(B, Lk, dtype=torch.uint8, device=dev)
+        # MOSES-like ragged lengths: l ~ N(35,8) clipped to [15, L]
+        lens = torch.clamp(torch.round(torch.randn(B, device=dev) * 8 + 35), 15, Lk).long()
+        lens[0] = Lk
+        pad = (torch.arange(Lk, device=dev)[None, :] < lens[:, None])
+        if causal:
+            mask = (pad[:, None, :] & torch.ones(Lq, Lk, dtype=torch.bool, device=dev).tril_()[None]).to(torch.uint8).contiguous()
+        else:
+            mask = pad.to(torch.uint8).contiguous()
         q, k, v = qkv, qkv[:, d:], qkv[:, 2 * d:]
         o, lse, _ = ops.attn_fwd(q, k, v, 3 * d, 3 * d, 3 * d, mask, B, H, Lq, Lk, dk, 0.1, 1, 1)
         do = torch.randn_like(o)
