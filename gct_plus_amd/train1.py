@@ -1,0 +1,170 @@
+"""Process bootstrap of the training job (reference train1.py:32-171).
+
+One process per GPU.  Launch either like the reference scripts do --
+`python train1.py -flags` (spawns one worker per visible GPU, Bashscript/train/*.sh) or
+`torchrun ... train1.py -flags` -- or under `python -m torch.distributed.run` with
+RANK/LOCAL_RANK/WORLD_SIZE set.  Differences from the reference, all forced by the build
+environment and none touching the arithmetic:
+  * torch DDP -> gct_plus_amd.dp.FlatDataParallel (RCCL all-reduce of the flat gradient buffer);
+  * torch.optim.Adam -> gct_plus_amd.optim.FusedAdam (same state_dict layout);
+  * data: the torchtext/rdkit pipeline (Utils/dataset.py, Model/collate_fn.py) is not part of
+    this build yet; `-synthetic N` trains on synthetic MOSES-shaped
+    token batches, otherwise pre-tokenised `{prepared_folder}/train_tokens.pt` /
+    `test_tokens.pt` (dicts with src/trg[/econds/dconds] tensors) are used.
+"""
+import argparse
+import logging
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from . import synthetic
+from .Configuration.config import train_opts
+from .Model.build_model import get_model
+from .Train.trainer1 import train_model
+from .dp import FlatDataParallel
+from .optim import FusedAdam
+
+
+def set_seed(seed):
+    """reference Utils/seed.py:7-18"""
+    if seed is None:
+        return
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+
+
+def get_logger(name, log_path):
+    """console + {model_folder}/records.log (reference Utils/log.py:26-43)"""
+    log = logging.getLogger(name)
+    log.setLevel(logging.INFO)
+    if not log.handlers:
+        fmt = logging.Formatter("%(asctime)s - %(levelname)s - %(message)s")
+        for h in (logging.StreamHandler(sys.stdout), logging.FileHandler(log_path)):
+            h.setFormatter(fmt)
+            log.addHandler(h)
+    return log
+
+
+class ShardedLoader:
+    """Minimal DataLoader+DistributedSampler stand-in over an in-HBM token dataset:
+    per-rank index shard (synthetic.shard_indices == DistributedSampler semantics), batches
+    of `batch_size` PER RANK (reference train1.py:83, Utils/dataset.py:304-329)."""
+
+    def __init__(self, data, batch_size, rank, world, shuffle, seed, device):
+        self.data = {k: v.to(device) for k, v in data.items()}
+        self.bs, self.rank, self.world, self.shuffle, self.seed = batch_size, rank, world, shuffle, seed
+        self.epoch = 0
+        self.n = next(iter(data.values())).size(0)
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        per_rank = -(-self.n // self.world)
+        return -(-per_rank // self.bs)
+
+    def __iter__(self):
+        idx = synthetic.shard_indices(self.n, self.world, self.rank, self.epoch, self.seed or 0,
+                                      self.shuffle)
+        idx = torch.tensor(idx, device=next(iter(self.data.values())).device)
+        for s in range(0, idx.numel(), self.bs):
+            sel = idx[s:s + self.bs]
+            yield {k: v.index_select(0, sel) for k, v in self.data.items()}
+
+
+def load_tokens(args, split, n_synth):
+    if n_synth > 0:
+        return synthetic.make_dataset(n_synth, args.max_strlen, args.model_type,
+                                      seed=0 if split == "train" else 1)
+    path = os.path.join(args.prepared_folder, f"{split}_tokens.pt")
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} not found. The torchtext/rdkit tokeniser of the reference is outside this "
+            "build's scope; pass -synthetic N or provide pre-tokenised tensors.")
+    return torch.load(path, weights_only=True)
+
+
+def main(rank, world_size, argv=None):
+    parser = argparse.ArgumentParser()
+    train_opts(parser)
+    args = parser.parse_args(argv)
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world_size > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world_size, device_id=device)
+    set_seed(args.seed)
+    os.makedirs(args.model_folder, exist_ok=True)
+    LOG = get_logger("train", os.path.join(args.model_folder, "records.log"))
+    LOG.info("random seed: %s", args.seed)
+    if rank == 0:
+        LOG.info(args)
+        LOG.info(f"world size: {world_size}")
+    if args.debug:
+        args.batch_size = 4
+    n_tr = 32 if (args.debug and args.synthetic) else args.synthetic
+    n_va = 32 if (args.debug and args.synthetic) else (args.synthetic_valid or max(args.synthetic // 10, 0))
+    train = load_tokens(args, "train", n_tr)
+    valid = load_tokens(args, "test", n_va)
+    nc = len(args.property_list)
+    if nc != synthetic.n_conds(args.model_type) and args.synthetic:
+        raise ValueError(f"-property_list has {nc} entries but {args.model_type} expects "
+                         f"{synthetic.n_conds(args.model_type)}")
+    train_loader = ShardedLoader(train, args.batch_size, rank, world_size, True, args.seed, device)
+    valid_loader = ShardedLoader(valid, args.batch_size, rank, world_size, False, args.seed, device)
+    if rank == 0:
+        LOG.info(f"# train / validation loader: {len(train_loader)} / {len(valid_loader)}")
+    src_vocab, trg_vocab = synthetic.vocab_sizes(args.model_type)
+    args.sos_id, args.eos_id, args.pad_id = synthetic.SOS_ID, synthetic.EOS_ID, synthetic.PAD_ID
+    if args.start_epoch > 1:
+        args.model_path = os.path.join(args.model_folder, f"model_{args.start_epoch-1}.pt")
+    model = get_model(args, src_vocab, trg_vocab, rank).cuda()
+    (model.sampler if hasattr(model, "sampler") else model.encoder).eps_mode = args.eps_mode
+    total = sum(p.numel() for p in model.parameters())
+    trainable = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    assert trainable > 0, "# trainable parameters = 0"
+    LOG.info(f"# total params: {total}, # train params: {trainable}")
+    inner = model
+    if world_size > 1:
+        model = FlatDataParallel(model)
+    optimizer = FusedAdam(inner.parameters(), lr=args.lr, betas=(args.lr_beta1, args.lr_beta2),
+                          eps=args.lr_eps, model=inner)
+    if args.start_epoch > 1:
+        ck = torch.load(args.model_path, map_location="cpu", weights_only=True)
+        optimizer.load_state_dict(ck["opt_state_dict"])
+    train_model(args, model, optimizer, train_loader, valid_loader, rank, world_size, LOG)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _worker(rank, world_size, argv):
+    os.environ["RANK"], os.environ["LOCAL_RANK"] = str(rank), str(rank)
+    os.environ["WORLD_SIZE"] = str(world_size)
+    main(rank, world_size, argv)
+
+
+def cli(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+        main(int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), argv)   # torchrun worker
+        return
+    n = torch.cuda.device_count()
+    print("device count:", n)
+    if n > 1:                                   # reference train1.py:156-166: one proc per GPU
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        mp.spawn(_worker, args=(n, argv), nprocs=n, join=True)
+    else:
+        main(0, 1, argv)

@@ -1,0 +1,140 @@
+"""CPU-only tests of the host side: C-ABI symbol table, flag surface, schedules, data sharding,
+mask builders, init-order parity of the product modules, flat-buffer bookkeeping."""
+import argparse
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from gct_plus_amd import _lib, synthetic
+from oracle import gct_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """include/gctplus_hip.h <-> _lib.SIGNATURES <-> the built .so (no compute call)."""
+    hdr = open(os.path.join(ROOT, "include", "gctplus_hip.h")).read()
+    declared = set(re.findall(r"\b(gct_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.gct_version() == _lib.ABI_VERSION
+    assert lib.gct_wgrad_ws_bytes(40960, 512, 512) > 0
+
+
+def test_ops_refuse_cpu_tensors():
+    from gct_plus_amd import ops
+    with pytest.raises(_lib.GctError):
+        ops.norm_fwd(torch.zeros(4, 8), torch.ones(8), torch.zeros(8))
+
+
+def test_missing_library_is_a_hard_error(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.GctError):
+        _lib.load()
+
+
+def test_train_flags_match_reference_surface():
+    from gct_plus_amd.Configuration.config import train_opts
+    p = argparse.ArgumentParser()
+    train_opts(p)
+    a = p.parse_args("-seed 1 -model_type pscavaetf -lr_WarmUpSteps 15000 -use_cond2lat -use_scaffold "
+                     "-start_epoch 1 -num_epoch 50 -batch_size 64 -property_list logP tPSA QED "
+                     "-model_folder ./Experiment/x".split())     # Bashscript/train/train_pscavaetf.sh
+    assert (a.N, a.H, a.d_ff, a.d_model, a.latent_dim, a.dropout) == (6, 8, 2048, 512, 128, 0.1)
+    assert (a.lr, a.lr_beta1, a.lr_beta2, a.lr_eps, a.lr_WarmUpSteps) == (1e-4, 0.9, 0.98, 1e-9, 15000)
+    assert (a.KLA_ini_beta, a.KLA_inc_beta, a.KLA_max_beta, a.KLA_beg_epoch) == (0.02, 0.02, 1.0, 1)
+    assert a.property_list == ["logP", "tPSA", "QED"] and a.use_cond2lat and not a.use_cond2dec
+
+
+def test_schedules_match_oracle():
+    from gct_plus_amd.Train.trainer1 import KLAnnealer, warmup_lr
+    for s in (1, 2, 100, 8000, 20000):
+        assert warmup_lr(s, 512, 8000) == O.warmup_lr(s, 512, 8000)
+    assert KLAnnealer(1, 0.02, 0.02, 1) == O.kl_beta(1) == pytest.approx(0.04)
+
+
+def test_masks_match_oracle_and_known_answers():
+    from gct_plus_amd.Model import get_src_mask, get_trg_mask, nopeak_mask
+    assert nopeak_mask(3, False, 1, 0).tolist() == [[[1, 0, 0], [1, 1, 0], [1, 1, 1]]]
+    assert nopeak_mask(2, True, 1, 2).tolist() == [[[1, 1, 1, 0], [1, 1, 1, 0], [1, 1, 1, 0], [1, 1, 1, 1]]]
+    assert nopeak_mask(3, False, 1, 0).dtype == torch.int64
+    ds = synthetic.make_dataset(5, 20, "pscavaetf", seed=3)
+    trg_in = ds["trg"][:, :-1]
+    assert torch.equal(get_src_mask(ds["src"], 1, ds["econds"]), O.get_src_mask(ds["src"], 1, ds["econds"]))
+    assert torch.equal(get_trg_mask(trg_in, 1, False, ds["dconds"]), O.get_trg_mask(trg_in, 1, False, ds["dconds"]))
+    assert torch.equal(get_trg_mask(trg_in, 1, True, ds["dconds"]), O.get_trg_mask(trg_in, 1, True, ds["dconds"]))
+
+
+@pytest.mark.parametrize("mtype", ["vaetf", "pvaetf", "scavaetf", "pscavaetf"])
+def test_product_modules_init_and_layout_parity(mtype):
+    """Same seed => bit-identical initial weights, same state_dict keys and parameter order as
+    the oracle (which is pinned to the reference by tests/golden)."""
+    from gct_plus_amd.Model import model_dict
+    vs, vt = synthetic.vocab_sizes(mtype)
+    nc = synthetic.n_conds(mtype)
+    kw = dict(N=2, d_model=64, dff=128, h=4, latent_dim=16)
+    torch.manual_seed(1)
+    m = model_dict[mtype](vs, vt, dropout=0.0, nconds=nc, use_cond2lat=True, **kw)
+    st = O.init_state(O.make_cfg(mtype, vs, vt, dropout=0.0, nconds=nc, use_cond2lat=True, **kw), seed=1)
+    sd = m.state_dict()
+    assert list(sd) == list(st)
+    assert all(torch.equal(sd[k], st[k]) for k in st)
+    cfg = O.make_cfg(mtype, vs, vt, dropout=0.0, nconds=nc, use_cond2lat=True, **kw)
+    assert [n for n, _ in m.named_parameters()] == O.param_names(cfg)
+
+
+def test_full_size_parameter_counts():
+    """SURVEY 8(a) a20 [probe]: 44 514 334 / 44 395 294 / 44 384 543 / 44 396 831 parameters."""
+    from gct_plus_amd.Model import model_dict
+    exp = {"vaetf": 44514334, "pvaetf": 44395294, "scavaetf": 44384543, "pscavaetf": 44396831}
+    for mtype, n in exp.items():
+        vs, vt = synthetic.vocab_sizes(mtype)
+        m = model_dict[mtype](vs, vt, N=6, d_model=512, dff=2048, h=8, latent_dim=128,
+                              nconds=synthetic.n_conds(mtype), use_cond2lat=True)
+        assert sum(p.numel() for p in m.parameters()) == n, mtype
+        assert len(m.state_dict()) == {"vaetf": 272, "pvaetf": 272, "scavaetf": 268, "pscavaetf": 272}[mtype]
+
+
+def test_flat_buffers_alias_parameters():
+    from gct_plus_amd.Model import model_dict
+    torch.manual_seed(0)
+    m = model_dict["pvaetf"](28, 30, N=1, d_model=64, dff=128, h=4, latent_dim=16, nconds=3, use_cond2lat=True)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    m.flatten_parameters()
+    flat = m.flat_params()
+    for (k, v) in m.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    p = next(m.parameters())
+    flat[:p.numel()] += 1.0
+    assert torch.equal(p.detach().flatten(), before[next(iter(before))].flatten() + 1.0)
+    for q in m.parameters():
+        assert q._gct_gview.shape == q.shape and q._gct_gview.data_ptr() % 16 == 0
+    m.sync_grads_to_flat()
+    assert all(q.grad is None or q.grad.data_ptr() == q._gct_gview.data_ptr() for q in m.parameters())
+
+
+def test_shard_indices_match_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+    data = list(range(1003))
+    for world in (1, 2, 8):
+        for rank in range(world):
+            for shuffle in (False, True):
+                s = DistributedSampler(data, num_replicas=world, rank=rank, shuffle=shuffle, seed=5, drop_last=False)
+                s.set_epoch(3)
+                assert list(s) == synthetic.shard_indices(len(data), world, rank, epoch=3, seed=5, shuffle=shuffle)
+
+
+def test_synthetic_layout():
+    ds = synthetic.make_dataset(64, 80, "pscavaetf", seed=0)
+    assert ds["src"].shape == (64, 80) and ds["trg"].shape == (64, 82) and ds["econds"].shape == (64, 3)
+    assert int(ds["src"].max()) < 29 and int(ds["trg"].max()) < 31
+    assert (ds["trg"][:, 0] == synthetic.SOS_ID).all() and (ds["src"][0] != synthetic.PAD_ID).all()
+    lens = (ds["src"] != 1).sum(1)
+    eos = ds["trg"].gather(1, (lens + 1).unsqueeze(1)).squeeze(1)
+    assert (eos == synthetic.EOS_ID).all()
