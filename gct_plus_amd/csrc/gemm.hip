@@ -18,6 +18,7 @@
 //   * "segmented" operands: q/k/v (mu/log_var) weights stay separate checkpoint tensors,
 //     the kernel selects the base pointer per 4-element chunk.
 #include <limits.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -61,9 +62,26 @@ struct GemmArgs {
   float keep_scale;
   uint32_t thr;
   GctRng rng;
+#ifdef GCT_STAMPS
+  unsigned long long* stamps;  // diagnostic build only (tools/gemm_stamps.hip)
+#endif
 };
 
 enum { EPI_SLAB = 32, EPI_D0 = 16 };
+
+#ifdef GCT_STAMPS
+#define STAMP(i)                                                                       \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    unsigned long long t__;                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");         \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    seg[i] += t__ - tprev;                                                             \
+    tprev = t__;                                                                       \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
 
 __device__ __forceinline__ const float* seg_ptr(const Seg3& s, int64_t idx, int64_t nper,
                                                 int64_t& local) {
@@ -188,30 +206,27 @@ __device__ __forceinline__ void store_rc(float* lds, const float4 (&r)[4], int t
   }
 }
 
-// ---- LDS -> fragments: frag[t][s] holds k = 16*h + s of free-dim index base+32t+(lane&31)
-__device__ __forceinline__ void frag_kc(float (&f)[2][16], const float* lds, int base, int lane) {
+// ---- LDS -> fragments, one QUARTER (4 k-values) at a time: f[t][e] holds k = 16*h + 4*c + e of
+// free-dim index base+32t+(lane&31).  KC: one ds_read_b128 per t; RC: four ds_read_b32 per t.
+__device__ __forceinline__ void fragq_kc(float (&f)[2][4], const float* lds, int base, int lane,
+                                         int c) {
   const int h = lane >> 5;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int row = base + t * 32 + (lane & 31);
     const int sw = (row >> 1) & 7;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float4 v = *reinterpret_cast<const float4*>(lds + row * BK + (((h * 4 + c) ^ sw) * 4));
-      f[t][c * 4 + 0] = v.x;
-      f[t][c * 4 + 1] = v.y;
-      f[t][c * 4 + 2] = v.z;
-      f[t][c * 4 + 3] = v.w;
-    }
+    const float4 v = *reinterpret_cast<const float4*>(lds + row * BK + (((h * 4 + c) ^ sw) * 4));
+    f[t][0] = v.x; f[t][1] = v.y; f[t][2] = v.z; f[t][3] = v.w;
   }
 }
-__device__ __forceinline__ void frag_rc(float (&f)[2][16], const float* lds, int base, int lane) {
+__device__ __forceinline__ void fragq_rc(float (&f)[2][4], const float* lds, int base, int lane,
+                                         int c) {
   const int h = lane >> 5;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int col = base + t * 32 + (lane & 31);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) f[t][s] = lds[(h * 16 + s) * BM + col];
+    for (int e = 0; e < 4; ++e) f[t][e] = lds[(h * 16 + c * 4 + e) * BM + col];
   }
 }
 
@@ -261,29 +276,55 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
   };
 
   const int64_t nkt = (kend - kbeg + BK - 1) / BK;
+#ifdef GCT_STAMPS
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#endif
   if (nkt > 0) {
     gload(kbeg);
     lstore(0);
   }
   __syncthreads();
+  STAMP(0);  // prologue
   for (int64_t kt = 0; kt < nkt; ++kt) {
     const int cur = (int)(kt & 1);
     if (kt + 1 < nkt) gload(kbeg + (kt + 1) * BK);  // in flight during the MFMAs below
+    STAMP(1);  // global load issue
     const float* la = lds + cur * 2 * TILE_FLOATS;
     const float* lb = la + TILE_FLOATS;
-    float fa[2][16], fb[2][16];
-    if (A_KC) frag_kc(fa, la, wm, lane); else frag_rc(fa, la, wm, lane);
-    if (B_KC) frag_kc(fb, lb, wn, lane); else frag_rc(fb, lb, wn, lane);
+    // fragments are prefetched ONE QUARTER (16 MFMAs = 1024 cycles) ahead of their use, so the
+    // LDS latency is always covered by a full MFMA group instead of two instructions
+    float fa[2][2][4], fb[2][2][4];
+    auto fragq = [&](int set, int c) {
+      if (A_KC) fragq_kc(fa[set], la, wm, lane, c); else fragq_rc(fa[set], la, wm, lane, c);
+      if (B_KC) fragq_kc(fb[set], lb, wn, lane, c); else fragq_rc(fb[set], lb, wn, lane, c);
+    };
+    fragq(0, 0);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
+    for (int c = 0; c < 4; ++c) {
+      const int set = c & 1;
+      if (c < 3) fragq(set ^ 1, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int e = 0; e < 4; ++e) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j],
+                                                             0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    STAMP(2);  // frag reads + 64 MFMAs
+#ifdef GCT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(3);  // wait for the prefetched tile
+#endif
     if (kt + 1 < nkt) lstore(cur ^ 1);
+    STAMP(4);  // LDS stores
     __syncthreads();
+    STAMP(5);  // barrier
   }
 
   // ---- epilogue: acc[i][j][r] -> C[row][col], col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
@@ -352,6 +393,267 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
       }
     }
   }
+#ifdef GCT_STAMPS
+  STAMP(6);  // epilogue
+  if (g.stamps && (threadIdx.x & 63) == 0 && blockIdx.x < 64) {
+    for (int i = 0; i < 8; ++i) g.stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + i] = seg[i];
+  }
+#endif
+}
+
+
+// =====================================================================================
+// FAST PATH kernel: same tiling/pipeline as gemm_f32_kernel, for the shapes that matter
+// (K % 32 == 0, 16-B aligned operands, segment boundaries aligned to the tile) with the two
+// costs the s_memtime stamps exposed removed:
+//   * tile loads: a wave-uniform 64-bit base (SGPRs, advanced per K-tile) + per-thread 32-bit
+//     offsets computed ONCE; edge rows/columns are clamped to valid memory instead of being
+//     predicated (they only feed accumulator rows/columns that are never stored) -- the loop
+//     issues 8 global_load_dwordx4 back to back with no address arithmetic or branches;
+//   * epilogue: each wave transposes its 64x64 accumulator block through LDS and every lane
+//     finishes a 4-row x 4-column patch: float4 bias/resid/pre accesses, one Philox call per
+//     column (4 rows each), float4 stores of 256 contiguous bytes per 16 lanes (was: 64 scalar
+//     stores per lane behind a per-element switch, 42k cycles per tile).
+// =====================================================================================
+struct FastEpi {
+  const GemmArgs& g;
+  __device__ __forceinline__ void apply(float4 (&v)[4], int64_t row0, int64_t col0,
+                                        float* cbase, int64_t cloc, float4 bias) const {
+    // v[rr] = 4 consecutive columns (col0..col0+3) of row row0+rr; row0 % 4 == 0
+    const int epi = g.epi;
+    uint4 bits[4];
+    const bool rng = g.thr != 0u && (epi == GCT_EPI_GELU_DROP || epi == GCT_EPI_DROP_RESID ||
+                                     epi == EPI_D0 + GCT_DEPI_GELU_BWD);
+    if (rng) {
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+        bits[cc] = gct_drop_bits(g.rng, (uint32_t)(row0 >> 2), (uint32_t)(col0 + cc));
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int64_t row = row0 + rr;
+      if (row >= g.M) break;
+      const int64_t off = row * g.ldc + cloc;
+      float x[4] = {v[rr].x, v[rr].y, v[rr].z, v[rr].w};
+      const float bs[4] = {bias.x, bias.y, bias.z, bias.w};
+      bool keep[4] = {true, true, true, true};
+      if (rng) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) keep[cc] = gct_pick(bits[cc], rr) >= g.thr;
+      }
+      if (epi == GCT_EPI_BIAS) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) x[cc] += bs[cc];
+      } else if (epi == GCT_EPI_GELU_DROP) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) x[cc] += bs[cc];
+        *reinterpret_cast<float4*>(g.pre + off) = make_float4(x[0], x[1], x[2], x[3]);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) x[cc] = keep[cc] ? gct_gelu(x[cc]) * g.keep_scale : 0.f;
+      } else if (epi == GCT_EPI_DROP_RESID) {
+        const float4 r = *reinterpret_cast<const float4*>(g.resid + off);
+        const float rs[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          x[cc] = (keep[cc] ? (x[cc] + bs[cc]) * g.keep_scale : 0.f) + rs[cc];
+      } else if (epi == EPI_D0 + GCT_DEPI_ACCUM) {
+        const float4 r = *reinterpret_cast<const float4*>(cbase + off);
+        x[0] += r.x; x[1] += r.y; x[2] += r.z; x[3] += r.w;
+      } else if (epi == EPI_D0 + GCT_DEPI_GELU_BWD) {
+        const float4 u = *reinterpret_cast<const float4*>(g.pre_in + off);
+        const float us[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          x[cc] = keep[cc] ? x[cc] * gct_gelu_grad(us[cc]) * g.keep_scale : 0.f;
+      }
+      *reinterpret_cast<float4*>(cbase + off) = make_float4(x[0], x[1], x[2], x[3]);
+    }
+  }
+};
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void
+gemm_f32_fast_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];  // A0 B0 A1 B1 : 64 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+  const unsigned tiles_n = (unsigned)((g.N + BN - 1) / BN);
+  const unsigned tiles_m = (unsigned)((g.M + BM - 1) / BM);
+  const unsigned per_split = tiles_m * tiles_n;
+  const unsigned lid = gct_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned z = lid / per_split, rest = lid - z * per_split;
+  const int64_t m0 = (int64_t)(rest / tiles_n) * BM, n0 = (int64_t)(rest % tiles_n) * BN;
+  const int64_t kbeg = (int64_t)z * g.ksplit;
+  const int64_t kend = (kbeg + g.ksplit < g.K) ? kbeg + g.ksplit : g.K;
+
+  // ---- per-thread invariant 32-bit offsets (floats), edges clamped into valid memory
+  uint32_t offa[4], offb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (A_KC) {
+      int64_t r = (tid >> 3) + 32 * i;
+      if (m0 + r > g.M - 1) r = g.M - 1 - m0;
+      offa[i] = (uint32_t)(r * g.lda + (tid & 7) * 4);
+    } else {
+      int64_t c = (tid & 31) * 4;
+      if (m0 + c > g.M - 4) c = g.M - 4 - m0;
+      offa[i] = (uint32_t)(((tid >> 5) + 8 * i) * g.lda + c);
+    }
+    if (B_KC) {
+      int64_t r = (tid >> 3) + 32 * i;
+      if (n0 + r > g.N - 1) r = g.N - 1 - n0;
+      offb[i] = (uint32_t)(r * g.ldb + (tid & 7) * 4);
+    } else {
+      int64_t c = (tid & 31) * 4;
+      if (n0 + c > g.N - 4) c = g.N - 4 - n0;
+      offb[i] = (uint32_t)(((tid >> 5) + 8 * i) * g.ldb + c);
+    }
+  }
+  // ---- wave-uniform tile bases; a K-tile (resp. the row/column tile) lies in ONE segment
+  auto useg = [](const Seg3& s, int64_t idx, int64_t nper, int64_t& local) -> const float* {
+    const bool g1 = idx >= nper, g2 = idx >= 2 * nper;
+    local = idx - (g2 ? 2 * nper : (g1 ? nper : 0));
+    return s.p0 + (g2 ? s.d2 : (g1 ? s.d1 : 0));
+  };
+  int64_t aloc_m, bloc_n;
+  const float* a_mbase = nullptr;
+  const float* b_nbase = nullptr;
+  if (!A_KC) a_mbase = useg(g.a, m0, g.a_nper, aloc_m) + aloc_m;                     // + k*lda
+  if (B_KC) b_nbase = useg(g.b, n0, g.b_nper, bloc_n) + bloc_n * g.ldb;             // + k
+  auto abase = [&](int64_t k0) -> const float* {
+    if (A_KC) {
+      int64_t loc;
+      const float* p = useg(g.a, k0, g.a_nper, loc);
+      return p + m0 * g.lda + loc;
+    }
+    return a_mbase + k0 * g.lda;
+  };
+  auto bbase = [&](int64_t k0) -> const float* {
+    if (B_KC) return b_nbase + k0;
+    int64_t loc;
+    const float* p = useg(g.b, k0, g.b_nper, loc);
+    return p + loc * g.ldb + n0;
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[4], rb[4];
+#define GCT_GLOAD(k0_)                                                                     \
+  do {                                                                                     \
+    const float* ab__ = abase(k0_);                                                        \
+    const float* bb__ = bbase(k0_);                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                          \
+        ra[i] = *reinterpret_cast<const float4*>(ab__ + offa[i]);                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                          \
+        rb[i] = *reinterpret_cast<const float4*>(bb__ + offb[i]);                          \
+  } while (0)
+#define GCT_LSTORE(buf_)                                                                   \
+  do {                                                                                     \
+    float* la__ = lds + (buf_) * 2 * TILE_FLOATS;                                          \
+    float* lb__ = la__ + TILE_FLOATS;                                                      \
+    if (A_KC) store_kc(la__, ra, tid); else store_rc(la__, ra, tid);                       \
+    if (B_KC) store_kc(lb__, rb, tid); else store_rc(lb__, rb, tid);                       \
+  } while (0)
+// the prefetched tile must stay in VGPRs until the MFMA block is done: an opaque use right
+// before the LDS stores stops hipcc from sinking the stores (and their vmcnt waits, and
+// scratch spills) to just behind the loads
+#define GCT_PIN(v_) asm volatile("" : "+v"(v_.x), "+v"(v_.y), "+v"(v_.z), "+v"(v_.w))
+
+  const int64_t nkt = (kend - kbeg) / BK;
+  if (nkt > 0) {
+    GCT_GLOAD(kbeg);
+    GCT_LSTORE(0);
+  }
+  __syncthreads();
+  for (int64_t kt = 0; kt < nkt; ++kt) {
+    const int cur = (int)(kt & 1);
+    const bool more = kt + 1 < nkt;
+    if (more) GCT_GLOAD(kbeg + (kt + 1) * BK);
+    __builtin_amdgcn_sched_barrier(0);
+    const float* la = lds + cur * 2 * TILE_FLOATS;
+    const float* lb = la + TILE_FLOATS;
+    float fa[2][2][4], fb[2][2][4];
+    if (A_KC) fragq_kc(fa[0], la, wm, lane, 0); else fragq_rc(fa[0], la, wm, lane, 0);
+    if (B_KC) fragq_kc(fb[0], lb, wn, lane, 0); else fragq_rc(fb[0], lb, wn, lane, 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int set = c & 1;
+      if (c < 3) {
+        if (A_KC) fragq_kc(fa[set ^ 1], la, wm, lane, c + 1); else fragq_rc(fa[set ^ 1], la, wm, lane, c + 1);
+        if (B_KC) fragq_kc(fb[set ^ 1], lb, wn, lane, c + 1); else fragq_rc(fb[set ^ 1], lb, wn, lane, c + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j],
+                                                             0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        GCT_PIN(ra[i]);
+        GCT_PIN(rb[i]);
+      }
+      GCT_LSTORE(cur ^ 1);
+    }
+    __syncthreads();
+  }
+#undef GCT_GLOAD
+#undef GCT_LSTORE
+#undef GCT_PIN
+
+  // ---- epilogue: per-wave 64x64 transpose through LDS (the tile buffers are free now)
+  float* stg = lds + wave * 4096;  // 64 rows x 64 cols
+  {
+    const int h = lane >> 5, c32 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stg[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + c32] = acc[i][j][r];
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes are visible to it
+  __builtin_amdgcn_wave_barrier();
+  const FastEpi ep{g};
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int rg = it * 4 + (lane >> 4), c4 = lane & 15;
+    const int64_t row0 = m0 + wm + rg * 4, col0 = n0 + wn + c4 * 4;
+    if (row0 >= g.M || col0 >= g.N) continue;
+    float4 v[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+      v[rr] = *reinterpret_cast<const float4*>(stg + (rg * 4 + rr) * 64 + c4 * 4);
+    float* cbase;
+    int64_t cloc;
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.epi == EPI_SLAB) {
+      cbase = g.c0 + (int64_t)z * g.slab_stride;
+      cloc = col0;
+    } else {
+      const bool g1 = col0 >= g.c_nper, g2 = col0 >= 2 * g.c_nper;
+      cloc = col0 - (g2 ? 2 * g.c_nper : (g1 ? g.c_nper : 0));
+      cbase = g.c0 + (g2 ? g.c_d2 : (g1 ? g.c_d1 : 0));
+      if (g.epi < EPI_D0 && g.bias0)
+        bias = *reinterpret_cast<const float4*>(g.bias0 + (g2 ? g.bias_d2 : (g1 ? g.bias_d1 : 0)) + cloc);
+    }
+    ep.apply(v, row0, col0, cbase, cloc, bias);
+  }
 }
 
 template <bool A_KC, bool B_KC>
@@ -363,7 +665,20 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st) {
     return GCT_ERR_ARG;
   }
   dim3 grid((unsigned)tiles), block(256);
-  if (vec)
+  static const bool no_fast = getenv("GCT_GEMM_NO_FAST") != nullptr;   // A/B switch for benchmarks
+  auto seg_ok = [](int64_t nper, int64_t extent, int64_t gran) { return nper >= extent || nper % gran == 0; };
+  const bool fast =
+      vec && !no_fast && g.K % BK == 0 && g.ksplit % BK == 0 && g.M >= 4 && g.N >= 4 &&
+      (A_KC ? seg_ok(g.a_nper, g.K, BK) : (seg_ok(g.a_nper, g.M, BM) && g.M % 4 == 0)) &&
+      (B_KC ? seg_ok(g.b_nper, g.N, BN) : (seg_ok(g.b_nper, g.K, BK) && g.N % 4 == 0)) &&
+      g.N % 4 == 0 && g.ldc % 4 == 0 && gct_aligned16(g.c0) && g.c_d1 % 4 == 0 && g.c_d2 % 4 == 0 &&
+      (g.c_nper >= g.N || g.c_nper % 4 == 0) && g.slab_stride % 4 == 0 &&
+      (!g.bias0 || (gct_aligned16(g.bias0) && g.bias_d1 % 4 == 0 && g.bias_d2 % 4 == 0)) &&
+      (!g.resid || gct_aligned16(g.resid)) && (!g.pre || gct_aligned16(g.pre)) &&
+      (!g.pre_in || gct_aligned16(g.pre_in)) && 130 * g.lda < (1ll << 31) && 130 * g.ldb < (1ll << 31);
+  if (fast)
+    hipLaunchKernelGGL((gemm_f32_fast_kernel<A_KC, B_KC>), grid, block, 0, st, g);
+  else if (vec)
     hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true>), grid, block, 0, st, g);
   else
     hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false>), grid, block, 0, st, g);

@@ -1,0 +1,35 @@
+"""End-to-end drop-in entry point on the GPU: train1 flags -> logs, CSVs, checkpoints, resume."""
+import os
+
+import pandas as pd
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train1_synthetic_two_epochs_and_resume(tmp_path):
+    from gct_plus_amd import train1
+    folder = str(tmp_path / "exp")
+    base = ("-seed 1 -use_cond2lat -model_type pvaetf -property_list logP tPSA QED -N 2 -d_model 64 -d_ff 128 "
+            f"-H 4 -latent_dim 16 -batch_size 16 -model_folder {folder} -synthetic 64 -synthetic_valid 32 "
+            "-max_strlen 24 -print_every 100").split()
+    train1.main(0, 1, base + "-start_epoch 1 -num_epoch 2".split())
+    for f in ("records.log", "train_1.csv", "valid_1.csv", "model_1.pt", "train_2.csv", "model_2.pt"):
+        assert os.path.exists(os.path.join(folder, f)), f
+    t1 = pd.read_csv(os.path.join(folder, "train_1.csv"), index_col=0)
+    assert list(t1.columns) == ["RCE", "KLD", "LOSS", "BETA", "LR"] and len(t1) == 4
+    assert abs(t1["BETA"].iloc[0] - 0.04) < 1e-12                       # epoch 1 beta
+    assert abs(t1["LR"].iloc[0] - 64 ** -0.5 * 8000 ** -1.5) < 1e-15    # lr written after step 1
+    t2 = pd.read_csv(os.path.join(folder, "train_2.csv"), index_col=0)
+    assert abs(t2["BETA"].iloc[0] - 0.06) < 1e-12
+    assert t1["LOSS"].notna().all() and t2["LOSS"].notna().all()
+    assert t2["RCE"].mean() < t1["RCE"].mean() * 1.05          # beta rises 0.04 -> 0.06, RCE must not
+    ck = torch.load(os.path.join(folder, "model_2.pt"), map_location="cpu", weights_only=True)
+    assert ck["model_params"]["nconds"] == 3 and ck["model_params"]["d_model"] == 64
+    assert len(ck["opt_state_dict"]["state"]) > 0
+    # resume at epoch 3 from model_2.pt (reference train1.py:97-99,125-129)
+    train1.main(0, 1, base + "-start_epoch 3 -num_epoch 3".split())
+    assert os.path.exists(os.path.join(folder, "model_3.pt"))
+    t3 = pd.read_csv(os.path.join(folder, "train_3.csv"), index_col=0)
+    assert abs(t3["LR"].iloc[0] - 64 ** -0.5 * 9 * 8000 ** -1.5) < 1e-15  # current_step continues at 8
