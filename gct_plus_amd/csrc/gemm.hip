@@ -567,50 +567,86 @@ gemm_f32_fast_kernel(const GemmArgs g) {
 #define GCT_PIN(v_) asm volatile("" : "+v"(v_.x), "+v"(v_.y), "+v"(v_.z), "+v"(v_.w))
 
   const int64_t nkt = (kend - kbeg) / BK;
+#ifdef GCT_STAMPS
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#endif
   if (nkt > 0) {
     GCT_GLOAD(kbeg);
     GCT_LSTORE(0);
   }
   __syncthreads();
+  STAMP(0);
+  // The loop body is ONE basic block (no branches: the last iteration re-loads the final tile
+  // and stores it to the idle LDS buffer, which nobody reads) so that the scheduler can
+  // interleave memory instructions with the MFMA stream:
+  //   quarter 0: the 8 global loads of tile t+1 trickle out, one per two MFMAs (issued as a
+  //              burst right after the barrier the 4 waves block ~750 cycles on the CU's
+  //              vector-memory issue path -- s_memtime stamps, tools/gemm_stamps.hip);
+  //   quarter 3: the 8 ds_write_b128 of tile t+1 (other LDS buffer), one per two MFMAs.
+  // Exposed per K-tile: the barrier and the first fragment read.
+  float fa[2][2][4], fb[2][2][4];
+#define GCT_FRAGQ(set_, c_, la_, lb_)                                                        \
+  do {                                                                                       \
+    if (A_KC) fragq_kc(fa[set_], la_, wm, lane, c_); else fragq_rc(fa[set_], la_, wm, lane, c_); \
+    if (B_KC) fragq_kc(fb[set_], lb_, wn, lane, c_); else fragq_rc(fb[set_], lb_, wn, lane, c_); \
+  } while (0)
+#define GCT_MFMA16(set_)                                                                     \
+  _Pragma("unroll") for (int e = 0; e < 4; ++e)                                              \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                              \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                              \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set_][i][e], fb[set_][j][e], acc[i][j], 0, 0, 0)
+  if (nkt > 0) GCT_FRAGQ(0, 0, lds, lds + TILE_FLOATS);
   for (int64_t kt = 0; kt < nkt; ++kt) {
     const int cur = (int)(kt & 1);
-    const bool more = kt + 1 < nkt;
-    if (more) GCT_GLOAD(kbeg + (kt + 1) * BK);
-    __builtin_amdgcn_sched_barrier(0);
     const float* la = lds + cur * 2 * TILE_FLOATS;
     const float* lb = la + TILE_FLOATS;
-    float fa[2][2][4], fb[2][2][4];
-    if (A_KC) fragq_kc(fa[0], la, wm, lane, 0); else fragq_rc(fa[0], la, wm, lane, 0);
-    if (B_KC) fragq_kc(fb[0], lb, wn, lane, 0); else fragq_rc(fb[0], lb, wn, lane, 0);
+    const int64_t knext = (kt + 1 < nkt) ? kbeg + (kt + 1) * BK : kbeg + kt * BK;
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- quarter 0
+    GCT_FRAGQ(1, 1, la, lb);
+    GCT_GLOAD(knext);
+    GCT_MFMA16(0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);  // fragment reads first
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int set = c & 1;
-      if (c < 3) {
-        if (A_KC) fragq_kc(fa[set ^ 1], la, wm, lane, c + 1); else fragq_rc(fa[set ^ 1], la, wm, lane, c + 1);
-        if (B_KC) fragq_kc(fb[set ^ 1], lb, wn, lane, c + 1); else fragq_rc(fb[set ^ 1], lb, wn, lane, c + 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j],
-                                                             0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+    for (int q = 0; q < 8; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 global load
     }
-    if (more) {
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(1);
+    // ---- quarter 1, 2
+    GCT_FRAGQ(0, 2, la, lb);
+    __builtin_amdgcn_sched_barrier(0);
+    GCT_MFMA16(1);
+    __builtin_amdgcn_sched_barrier(0);
+    GCT_FRAGQ(1, 3, la, lb);
+    __builtin_amdgcn_sched_barrier(0);
+    GCT_MFMA16(0);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(2);
+    // ---- quarter 3 + LDS stores of the next tile
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        GCT_PIN(ra[i]);
-        GCT_PIN(rb[i]);
-      }
-      GCT_LSTORE(cur ^ 1);
+    for (int i = 0; i < 4; ++i) {
+      GCT_PIN(ra[i]);
+      GCT_PIN(rb[i]);
     }
+    GCT_LSTORE(cur ^ 1);
+    GCT_MFMA16(1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 LDS store
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(3);
     __syncthreads();
+    STAMP(4);
+    GCT_FRAGQ(0, 0, lds + (cur ^ 1) * 2 * TILE_FLOATS, lds + (cur ^ 1) * 2 * TILE_FLOATS + TILE_FLOATS);
   }
+  __syncthreads();  // the speculative fragment read above must finish before LDS is reused
+#undef GCT_FRAGQ
+#undef GCT_MFMA16
 #undef GCT_GLOAD
 #undef GCT_LSTORE
 #undef GCT_PIN
@@ -654,6 +690,12 @@ gemm_f32_fast_kernel(const GemmArgs g) {
     }
     ep.apply(v, row0, col0, cbase, cloc, bias);
   }
+#ifdef GCT_STAMPS
+  STAMP(6);  // epilogue
+  if (g.stamps && (threadIdx.x & 63) == 0 && blockIdx.x < 64) {
+    for (int i = 0; i < 8; ++i) g.stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + i] = seg[i];
+  }
+#endif
 }
 
 template <bool A_KC, bool B_KC>

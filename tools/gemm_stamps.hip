@@ -27,10 +27,10 @@ static void run(int64_t M, int K, int N, int extra_lds) {
   g.c0 = y; g.ldc = N; g.c_nper = N; g.ksplit = K; g.nsplit = 1; g.epi = GCT_EPI_BIAS; g.bias0 = b;
   g.stamps = st;
   const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
-  if (extra_lds) hipFuncSetAttribute((const void*)gemm_f32_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  if (extra_lds) hipFuncSetAttribute((const void*)gemm_f32_fast_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   for (int rep = 0; rep < 3; ++rep) {
     hipMemset(st, 0, 64 * 4 * 8 * 8);
-    hipLaunchKernelGGL((gemm_f32_kernel<true, true, true>), dim3((unsigned)tiles), dim3(256), extra_lds, 0, g);
+    hipLaunchKernelGGL((gemm_f32_fast_kernel<true, true>), dim3((unsigned)tiles), dim3(256), extra_lds, 0, g);
     hipDeviceSynchronize();
   }
   std::vector<unsigned long long> hs(64 * 4 * 8);
@@ -38,7 +38,7 @@ static void run(int64_t M, int K, int N, int extra_lds) {
   double seg[8] = {0};
   for (int wv = 0; wv < 64 * 4; ++wv) for (int i = 0; i < 8; ++i) seg[i] += (double)hs[wv * 8 + i] / (64 * 4);
   double tot = 0; for (int i = 0; i < 8; ++i) tot += seg[i];
-  const char* nm[8] = {"prologue", "gload issue", "frag+MFMA", "vmcnt wait", "lds store", "barrier", "epilogue", "-"};
+  const char* nm[8] = {"prologue", "Q0 (+gloads)", "Q1+Q2", "Q3 (+ldsw)", "barrier", "-", "epilogue", "-"};
   printf("M=%ld K=%d N=%d extra_lds=%d: wave lifetime %.0f cycles, k-tiles %d\n", (long)M, K, N, extra_lds, tot, K / 32);
   for (int i = 0; i < 7; ++i) printf("   %-12s %9.0f cyc  %5.1f %%   (%.0f per k-tile)\n", nm[i], seg[i], 100 * seg[i] / tot, seg[i] / (K / 32));
   hipFree(x); hipFree(w); hipFree(b); hipFree(y); hipFree(st);
