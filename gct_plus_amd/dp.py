@@ -28,11 +28,15 @@ class FlatDataParallel(nn.Module):
         self._flat_ok = getattr(module, "_gct_flat", None) is not None
         self._pending = False
         with torch.no_grad():
-            if self._flat_ok:
-                dist.broadcast(module.flat_params(), src=0, group=process_group)
-            else:
-                for p in module.parameters():
-                    dist.broadcast(p.data, src=0, group=process_group)
+            bufs = [module.flat_params()] if self._flat_ok else [p.data for p in module.parameters()]
+            staged = dist.get_backend(process_group) != "nccl" and bufs[0].is_cuda
+            for b in bufs:
+                if staged:
+                    h = b.cpu()
+                    dist.broadcast(h, src=0, group=process_group)
+                    b.copy_(h)
+                else:
+                    dist.broadcast(b, src=0, group=process_group)
         self._avg_native = dist.get_backend(process_group) == "nccl"
 
     def forward(self, *args, **kwargs):
@@ -78,4 +82,17 @@ class FlatDataParallel(nn.Module):
 
     def _allreduce(self, t):
         op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
+        if t.is_cuda and not self._avg_native:
+            # test-only route (gloo ranks sharing one GPU): stage through host memory
+            return _HostStaged(t, self.pg)
         return dist.all_reduce(t, op=op, group=self.pg, async_op=True)
+
+
+class _HostStaged:
+    def __init__(self, t, pg):
+        self.t, self.h = t, t.detach().cpu()
+        self.w = dist.all_reduce(self.h, op=dist.ReduceOp.SUM, group=pg, async_op=True)
+
+    def wait(self):
+        self.w.wait()
+        self.t.copy_(self.h)
