@@ -3,12 +3,17 @@ xGMI (torch.distributed backend "nccl" IS RCCL on ROCm).
 
 Replaces torch.nn.parallel.DistributedDataParallel at train1.py:111-112 of the reference:
   * construction broadcasts the flat parameter buffer from rank 0 (DDP ctor semantics);
-  * after every backward the model's flat gradient buffer (one contiguous 178 MB range, see
-    flat.py) is all-reduced and averaged (DDP's mean-of-per-rank-sum-losses semantics,
-    SURVEY.md 2.3) -- a few large collectives instead of DDP's 25 MB bucket copies;
+  * the model's flat gradient buffer (one contiguous 178 MB range, see flat.py) is split into
+    a few contiguous BUCKETS along trunk boundaries (encoder | decoder+heads).  A bucket's
+    averaged all-reduce (ReduceOp.AVG: DDP's mean-of-per-rank-sum-loss gradients, SURVEY.md
+    2.3) is launched from post-accumulate-grad hooks the moment its last gradient has been
+    written -- the decoder-side exchange (57 % of the bytes) runs on RCCL's stream while the
+    encoder trunk is still in its backward pass; whatever is left is launched, and everything
+    is waited for, in an end-of-backward callback.  Large contiguous messages, no bucket
+    copies (DDP's 25 MB buckets copy every gradient twice);
   * the `pe` buffers are constants, so DDP's per-forward buffer broadcast is dropped;
-  * parameters that received no gradient (Vaetf's dead encoder.fc_*) contribute zeros
-    instead of tripping DDP's unused-parameter check.
+  * parameters that receive no gradient (Vaetf's dead encoder.fc_*, learned after the first
+    backward) contribute zeros instead of tripping DDP's unused-parameter check.
 state_dict() keys carry the 'module.' prefix exactly like a DDP-wrapped reference model
 (Train/trainer1.py:42 saves from the wrapper; Model/build_model.py:70-71 strips it)."""
 from __future__ import annotations
@@ -18,18 +23,31 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+class _HostStaged:
+    """test-only route (gloo ranks sharing one GPU): stage the collective through host memory"""
+
+    def __init__(self, t, pg):
+        self.t, self.h = t, t.detach().cpu()
+        self.w = dist.all_reduce(self.h, op=dist.ReduceOp.SUM, group=pg, async_op=True)
+
+    def wait(self):
+        self.w.wait()
+        self.t.copy_(self.h)
+
+
 class FlatDataParallel(nn.Module):
-    def __init__(self, module: nn.Module, n_chunks: int = 4, process_group=None):
+    def __init__(self, module: nn.Module, process_group=None, overlap: bool = True):
         super().__init__()
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
-        self.n_chunks = max(1, n_chunks)
+        self.overlap = overlap
         self._flat_ok = getattr(module, "_gct_flat", None) is not None
-        self._pending = False
+        self._armed = False
+        self._avg_native = dist.get_backend(process_group) == "nccl"
         with torch.no_grad():
             bufs = [module.flat_params()] if self._flat_ok else [p.data for p in module.parameters()]
-            staged = dist.get_backend(process_group) != "nccl" and bufs[0].is_cuda
+            staged = (not self._avg_native) and bufs[0].is_cuda
             for b in bufs:
                 if staged:
                     h = b.cpu()
@@ -37,8 +55,64 @@ class FlatDataParallel(nn.Module):
                     b.copy_(h)
                 else:
                     dist.broadcast(b, src=0, group=process_group)
-        self._avg_native = dist.get_backend(process_group) == "nccl"
+        self._buckets = []
+        if self._flat_ok:
+            self._make_buckets()
 
+    # ------------------------------------------------------------------ bucket bookkeeping
+    def _make_buckets(self):
+        flat = self.module._gct_flat
+        order, offs, total = flat["order"], flat["offsets"], flat["numel"]
+        names = {id(p): n for n, p in self.module.named_parameters()}
+        groups = []                                   # contiguous runs by top-level sub-module
+        for p, o in zip(order, offs):
+            top = "encoder" if names[id(p)].startswith("encoder.") else "rest"
+            if not groups or groups[-1]["top"] != top:
+                groups.append({"top": top, "start": o, "params": []})
+            groups[-1]["params"].append(p)
+        for i, g in enumerate(groups):
+            g["end"] = groups[i + 1]["start"] if i + 1 < len(groups) else total
+        self._buckets = groups
+        self._bucket_of = {}
+        for bi, g in enumerate(groups):
+            for p in g["params"]:
+                self._bucket_of[id(p)] = bi
+                if self.overlap and p.requires_grad:
+                    p.register_post_accumulate_grad_hook(self._on_grad)
+        self._dead = set()                            # ids of params that never get a gradient
+        self._learned = False
+        self._reset_round()
+
+    def _reset_round(self):
+        self._fired = set()
+        self._works = []
+        self._launched = [False] * len(self._buckets)
+        self._left = [sum(1 for p in g["params"] if p.requires_grad and id(p) not in self._dead)
+                      for g in self._buckets]
+
+    def _on_grad(self, p):
+        if not self._armed or id(p) in self._fired:
+            return
+        self._fired.add(id(p))
+        bi = self._bucket_of[id(p)]
+        self._left[bi] -= 1
+        if self._left[bi] == 0 and self._learned and not self._launched[bi]:
+            self._launch(bi)
+
+    @torch.no_grad()
+    def _launch(self, bi):
+        g = self._buckets[bi]
+        for p in g["params"]:                          # stray / missing gradients -> flat slots
+            if p.grad is None:
+                p._gct_gview.zero_()
+            elif p.grad.data_ptr() != p._gct_gview.data_ptr():
+                p._gct_gview.copy_(p.grad)
+                p.grad = p._gct_gview
+        t = self.module.flat_grads()[g["start"]:g["end"]]
+        self._works.append((self._allreduce(t), t))
+        self._launched[bi] = True
+
+    # ------------------------------------------------------------------------- forward/hooks
     def forward(self, *args, **kwargs):
         out = self.module(*args, **kwargs)
         if torch.is_grad_enabled():
@@ -51,27 +125,30 @@ class FlatDataParallel(nn.Module):
     # the hook on the first output gradient queues a callback that fires once the whole
     # backward pass (every AccumulateGrad) has finished
     def _arm(self, grad):
-        if not self._pending:
-            self._pending = True
-            torch.autograd.Variable._execution_engine.queue_callback(self._reduce)
+        if not self._armed:
+            self._armed = True
+            if self._flat_ok:
+                self._reset_round()
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
         return grad
 
     @torch.no_grad()
-    def _reduce(self):
-        self._pending = False
+    def _finalize(self):
+        self._armed = False
         m = self.module
         if self._flat_ok:
-            m.sync_grads_to_flat()
-            flat = m.flat_grads()
-            n = flat.numel()
-            step = (n + self.n_chunks - 1) // self.n_chunks
-            works = []
-            for s in range(0, n, step):
-                works.append(self._allreduce(flat[s:s + step]))
-            for w in works:
+            if not self._learned:                      # first backward: learn the dead set
+                self._dead = {id(p) for g in self._buckets for p in g["params"]
+                              if p.requires_grad and id(p) not in self._fired} if self.overlap else set()
+                self._learned = True
+            for bi in range(len(self._buckets)):
+                if not self._launched[bi]:
+                    self._launch(bi)
+            for w, t in self._works:
                 w.wait()
-            if not self._avg_native:
-                flat.mul_(1.0 / self.world)
+                if not self._avg_native:
+                    t.mul_(1.0 / self.world)
+            self._works = []
         else:
             for p in m.parameters():
                 if p.grad is None:
@@ -81,18 +158,7 @@ class FlatDataParallel(nn.Module):
                     p.grad.mul_(1.0 / self.world)
 
     def _allreduce(self, t):
-        op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
         if t.is_cuda and not self._avg_native:
-            # test-only route (gloo ranks sharing one GPU): stage through host memory
             return _HostStaged(t, self.pg)
+        op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
         return dist.all_reduce(t, op=op, group=self.pg, async_op=True)
-
-
-class _HostStaged:
-    def __init__(self, t, pg):
-        self.t, self.h = t, t.detach().cpu()
-        self.w = dist.all_reduce(self.h, op=dist.ReduceOp.SUM, group=pg, async_op=True)
-
-    def wait(self):
-        self.w.wait()
-        self.t.copy_(self.h)
