@@ -1,0 +1,173 @@
+// KV-cached autoregressive decode helpers (reference
+// Inference/sampling_tool.py:140-184 re-runs the WHOLE decoder on ys[:, :i+1] every step).
+//   gct_attn_decode  : one query row per (sample, head) against cached keys/values
+//   gct_select_token : softmax over the vocabulary + greedy / multinomial choice, appends the
+//                      token, updates the key-valid flags and the per-sample finished mask
+// Both are tiny and HBM/latency-bound; they exist so a whole decode step is a fixed kernel
+// chain with no host round trip (graph-capturable).
+#include "common.h"
+
+namespace {
+
+// one wave per (b, h); 16 lanes per key for the scores (4 keys per pass), lanes over d for P.V
+template <int DK>
+__global__ __launch_bounds__(256) void attn_decode_kernel(
+    const float* __restrict__ q, int64_t ldq, const float* __restrict__ k, const float* __restrict__ v,
+    int64_t kv_row, int64_t kv_batch, const uint8_t* __restrict__ valid, int64_t valid_sb,
+    float* __restrict__ o, int64_t ldo, int n, int H, int Lc, float scale) {
+  __shared__ float sc[4][128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
+  if (pair >= (int64_t)n * H) return;
+  const int b = (int)(pair / H), h = (int)(pair - (int64_t)b * H);
+  const float* qp = q + (int64_t)b * ldq + h * DK;
+  const float* kp = k + (int64_t)b * kv_batch + h * DK;
+  const float* vp = v + (int64_t)b * kv_batch + h * DK;
+  const uint8_t* vl = valid ? valid + (int64_t)b * valid_sb : nullptr;
+  constexpr int LPK = DK / 4;        // lanes per key (float4 each)
+  constexpr int KPP = 64 / LPK;      // keys per pass
+  const int sub = lane % LPK, kslot = lane / LPK;
+  const float4 qv = *reinterpret_cast<const float4*>(qp + sub * 4);
+  float m = -INFINITY;
+  for (int j0 = 0; j0 < Lc; j0 += KPP) {
+    const int j = j0 + kslot;
+    float s = 0.f;
+    if (j < Lc) {
+      const float4 kv4 = *reinterpret_cast<const float4*>(kp + (int64_t)j * kv_row + sub * 4);
+      s = (qv.x * kv4.x + qv.y * kv4.y) + (qv.z * kv4.z + qv.w * kv4.w);
+    }
+#pragma unroll
+    for (int off = LPK / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (j < Lc && sub == 0) {
+      s *= scale;
+      if (vl && vl[j] == 0) s = -1e9f;            // masked_fill(mask == 0, -1e9)
+      sc[wave][j] = s;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  for (int j = lane; j < Lc; j += 64) m = fmaxf(m, sc[wave][j]);
+  m = gct_wave_max(m);
+  float l = 0.f;
+  for (int j = lane; j < Lc; j += 64) {
+    const float e = expf(sc[wave][j] - m);
+    sc[wave][j] = e;
+    l += e;
+  }
+  l = gct_wave_sum(l);
+  const float inv = 1.0f / l;
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < DK) {
+    float acc = 0.f;
+    for (int j = 0; j < Lc; ++j) acc = fmaf(sc[wave][j] * inv, vp[(int64_t)j * kv_row + lane], acc);
+    o[(int64_t)b * ldo + h * DK + lane] = acc;
+  }
+}
+
+__device__ __forceinline__ float u01_open(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// one wave per sample row
+__global__ __launch_bounds__(256) void select_token_kernel(const float* __restrict__ logits, int V,
+                                                           int64_t* ys, int64_t ld_ys, int pos,
+                                                           uint8_t* valid, int64_t valid_sb,
+                                                           uint8_t* done, float* probs_out, int n,
+                                                           int mode, int64_t pad_id, int64_t eos_id,
+                                                           GctRng rng) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= n) return;
+  const float* lr = logits + (int64_t)row * V;
+  float mx = -INFINITY;
+  for (int c = lane; c < V; c += 64) mx = fmaxf(mx, lr[c]);
+  mx = gct_wave_max(mx);
+  float se = 0.f;
+  for (int c = lane; c < V; c += 64) se += expf(lr[c] - mx);
+  se = gct_wave_sum(se);
+  const float inv = 1.0f / se;
+  int best = 0;
+  if (mode == 0) {
+    // greedy: first index of the maximum probability (torch.max semantics)
+    float bp = -1.f;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < V; c += 64) {
+      const float p = expf(lr[c] - mx) * inv;
+      if (probs_out) probs_out[(int64_t)row * V + c] = p;
+      if (p > bp) { bp = p; bi = c; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float op = __shfl_xor(bp, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (op > bp || (op == bp && oi < bi)) { bp = op; bi = oi; }
+    }
+    best = bi;
+  } else {
+    // multinomial: inverse CDF with one Philox uniform per (row, position)
+    const uint4 r = gct_philox(rng, (uint32_t)row, (uint32_t)pos, 0x452821E6u, 0x38D01377u);
+    const float u = u01_open(r.x);
+    float cum = 0.f;
+    int pick = V - 1;
+    bool found = false;
+    for (int c0 = 0; c0 < V; c0 += 64) {
+      const int c = c0 + lane;
+      float p = c < V ? expf(lr[c] - mx) * inv : 0.f;
+      if (probs_out && c < V) probs_out[(int64_t)row * V + c] = p;
+      float incl = p;                                   // inclusive scan over the wave
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const float t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+      }
+      const bool hit = !found && c < V && (cum + incl) > u;
+      const unsigned long long ball = __ballot(hit);
+      if (ball && !found) {
+        pick = c0 + (int)__builtin_ctzll(ball);
+        found = true;
+      }
+      cum += __shfl(incl, 63, 64);
+    }
+    best = pick;
+  }
+  if (lane == 0) {
+    ys[(int64_t)row * ld_ys + pos] = best;
+    if (valid) valid[(int64_t)row * valid_sb + pos] = (best != pad_id) ? 1 : 0;
+    if (done && best == eos_id) done[row] = 1;
+  }
+}
+
+}  // namespace
+
+extern "C" int gct_attn_decode(const float* q, int64_t ldq, const float* k, const float* v,
+                               int64_t kv_row, int64_t kv_batch, const uint8_t* valid,
+                               int64_t valid_sb, float* o, int64_t ldo, int n, int H, int Lc, int dk,
+                               float scale, void* stream) {
+  GCT_CHECK_ARG(q && k && v && o && n >= 0 && H > 0 && Lc > 0 && Lc <= 128, "attn_decode: bad args");
+  GCT_CHECK_ARG(dk == 16 || dk == 32 || dk == 64, "attn_decode: head dim %d unsupported", dk);
+  GCT_CHECK_ARG(ldq % 4 == 0 && kv_row % 4 == 0 && kv_batch % 4 == 0 && gct_aligned16(q) &&
+                    gct_aligned16(k) && gct_aligned16(v),
+                "attn_decode: operands must be 16-B aligned");
+  if (n == 0) return GCT_OK;
+  const int64_t pairs = (int64_t)n * H;
+  dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dk == 64) hipLaunchKernelGGL(attn_decode_kernel<64>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale);
+  else if (dk == 32) hipLaunchKernelGGL(attn_decode_kernel<32>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale);
+  else hipLaunchKernelGGL(attn_decode_kernel<16>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale);
+  GCT_LAUNCH_CHECK("attn_decode");
+  return GCT_OK;
+}
+
+extern "C" int gct_select_token(const float* logits, int V, int64_t* ys, int64_t ld_ys, int pos,
+                                uint8_t* valid, int64_t valid_sb, uint8_t* done, float* probs_out,
+                                int n, int mode, int64_t pad_id, int64_t eos_id, uint64_t seed,
+                                void* stream) {
+  GCT_CHECK_ARG(logits && ys && V > 0 && n >= 0 && pos >= 0 && (mode == 0 || mode == 1),
+                "select_token: bad args");
+  if (n == 0) return GCT_OK;
+  hipLaunchKernelGGL(select_token_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, logits, V, ys, ld_ys, pos, valid, valid_sb, done, probs_out,
+                     n, mode, pad_id, eos_id, gct_rng_make(seed, 0xDEC0DEu));
+  GCT_LAUNCH_CHECK("select_token");
+  return GCT_OK;
+}

@@ -172,6 +172,22 @@ int gct_ce_bwd(const float* logits, const int64_t* target, const float* gout, fl
 int gct_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
                   float b2, float eps, int64_t step, float gscale, void* stream);
 
+/* --------------------------------------------------------- K11: KV-cached decode */
+/* Inference/sampling_tool.py:140-184 re-runs the whole decoder on ys[:, :i+1] each step; these
+ * two kernels (with the GEMM/norm/embedding entry points above) make one step a fixed chain.
+ * gct_attn_decode: ONE query row per (sample, head): q [n][H*dk] (ld ldq); keys/values row j of
+ * sample b at k + b*kv_batch + j*kv_row (+ h*dk); valid (nullable) uint8 [n][>=Lc], 0 => -1e9;
+ * o [n][H*dk].  Lc <= 128. */
+int gct_attn_decode(const float* q, int64_t ldq, const float* k, const float* v, int64_t kv_row,
+                    int64_t kv_batch, const uint8_t* valid, int64_t valid_sb, float* o, int64_t ldo,
+                    int n, int H, int Lc, int dk, float scale, void* stream);
+/* softmax(logits[n][V]) then mode 0: argmax (first maximum, torch.max semantics) / mode 1:
+ * multinomial (Philox inverse-CDF).  Writes ys[row*ld_ys + pos], valid[row*valid_sb + pos] =
+ * (token != pad), done[row] |= (token == eos); probs_out (nullable) [n][V]. */
+int gct_select_token(const float* logits, int V, int64_t* ys, int64_t ld_ys, int pos, uint8_t* valid,
+                     int64_t valid_sb, uint8_t* done, float* probs_out, int n, int mode,
+                     int64_t pad_id, int64_t eos_id, uint64_t seed, void* stream);
+
 /* ------------------------------------------------------------------ utilities */
 /* dst[(r / rpb)*dst_rpb + dst_off + r % rpb][:] (op)= src[(r / rpb)*src_rpb + src_off + r % rpb][:]
  * row gather/scatter used for the cond2lat concat (Model/vaetf.py:88-91). accumulate: += */

@@ -1,0 +1,81 @@
+"""KV-cached decode parity: token ids must equal (a) the reference's greedy ids frozen in
+tests/golden/g5_decode.pt and (b) the reference-style loop over the un-cached model.decode."""
+import os
+
+import pytest
+import torch
+
+from gct_plus_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+TINY = dict(N=2, d_model=64, dff=128, h=4, latent_dim=16)
+
+
+def build(mtype, full=False, seed=1):
+    from gct_plus_amd.Model import model_dict
+    vs, vt = synthetic.vocab_sizes(mtype)
+    kw = dict(N=6, d_model=512, dff=2048, h=8, latent_dim=128) if full else TINY
+    torch.manual_seed(seed)
+    return model_dict[mtype](vs, vt, dropout=0.1, nconds=synthetic.n_conds(mtype), use_cond2lat=True,
+                             **kw).cuda().eval()
+
+
+def test_kv_decode_matches_reference_golden_ids(golden_dir):
+    from gct_plus_amd.decode import KVDecoder
+    g5 = torch.load(os.path.join(golden_dir, "g5_decode.pt"), weights_only=True)
+    for mtype, fx in g5.items():
+        model = build(mtype)
+        z = fx["z"].cuda()
+        dconds = fx["dconds"].cuda() if fx["dconds"] is not None else None
+        n, L = z.shape[0], z.shape[1]
+        src_mask = torch.ones(n, 1, L, dtype=torch.bool, device="cuda")
+        kd = KVDecoder(model, synthetic.PAD_ID, synthetic.SOS_ID, eos_id=-1)   # fixture ran all 15 steps
+        kd.start(z, src_mask, dconds, max_total_len=32)
+        ys0 = torch.full((n, 1), synthetic.SOS_ID, dtype=torch.long, device="cuda")
+        ys = kd.generate(ys0, max_strlen=16)
+        assert torch.equal(ys.cpu(), fx["ys"]), mtype
+        assert torch.allclose(kd.buf["logits"].cpu(), fx["last_logits"], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("mtype,graphs", [("vaetf", False), ("pscavaetf", False), ("vaetf", True)])
+def test_kv_decode_matches_uncached_full_size(mtype, graphs):
+    """Full-size model, ragged source masks, a scaffold-style prefix for pscavaetf, early <eos> stop."""
+    from gct_plus_amd.decode import KVDecoder, reference_style_decode
+    model = build(mtype, full=True, seed=3)
+    nc = synthetic.n_conds(mtype)
+    n, Le = 24, 40 + nc
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn(n, Le, 128, generator=g).cuda()
+    dconds = torch.randn(n, nc, generator=g).cuda() if nc else None
+    lens = torch.randint(10, Le + 1, (n,), generator=g)
+    src_mask = (torch.arange(Le)[None, :] < lens[:, None]).unsqueeze(1).cuda()
+    if nc:
+        pre = torch.randint(5, 30, (n, 6), generator=g)
+        ys0 = torch.cat([torch.full((n, 1), synthetic.SOS_ID), pre, torch.full((n, 1), 4)], 1).cuda()
+    else:
+        ys0 = torch.full((n, 1), synthetic.SOS_ID, dtype=torch.long, device="cuda")
+    ref = reference_style_decode(model, z, src_mask, dconds, ys0, synthetic.PAD_ID, synthetic.EOS_ID, 40)
+    kd = KVDecoder(model, synthetic.PAD_ID, synthetic.SOS_ID, synthetic.EOS_ID)
+    kd.start(z, src_mask, dconds, max_total_len=64)
+    ys = kd.generate(ys0, max_strlen=40, use_graphs=graphs)
+    assert ys.shape == ref.shape, (ys.shape, ref.shape)
+    assert torch.equal(ys, ref)
+
+
+def test_multinomial_matches_probabilities():
+    """Sampling cannot share an RNG stream with torch.multinomial; compare at the probability
+    level: empirical frequencies of the first sampled token vs softmax(logits)."""
+    from gct_plus_amd import ops
+    n, V = 4096, 30
+    logits = torch.randn(1, V, generator=torch.Generator().manual_seed(0)).repeat(n, 1).cuda().contiguous()
+    ys = torch.zeros(n, 2, dtype=torch.int64, device="cuda")
+    valid = torch.zeros(n, 2, dtype=torch.uint8, device="cuda")
+    done = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    probs = torch.empty(n, V, device="cuda")
+    ops.select_token(logits, ys, 1, valid, done, 1, synthetic.PAD_ID, synthetic.EOS_ID, seed=123, probs_out=probs)
+    p = torch.softmax(logits[0].double().cpu(), -1)
+    assert torch.allclose(probs[0].double().cpu(), p, atol=1e-6)
+    freq = torch.bincount(ys[:, 1].cpu(), minlength=V).double() / n
+    assert float((freq - p).abs().max()) < 0.03
+    assert torch.equal(valid[:, 1].cpu().bool(), ys[:, 1].cpu() != synthetic.PAD_ID)
+    assert torch.equal(done.cpu().bool(), ys[:, 1].cpu() == synthetic.EOS_ID)
