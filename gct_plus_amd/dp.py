@@ -44,10 +44,21 @@ class FlatDataParallel(nn.Module):
         self.overlap = overlap
         self._flat_ok = getattr(module, "_gct_flat", None) is not None
         self._armed = False
-        self._avg_native = dist.get_backend(process_group) == "nccl"
+        self._nccl = dist.get_backend(process_group) == "nccl"
+        self._avg_native = self._nccl
+        if self._nccl:
+            # RCCL normally provides ReduceOp.AVG; probe once, fall back to SUM + scale if not
+            try:
+                probe = torch.ones(4, device=next(module.parameters()).device)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=process_group)
+                torch.cuda.synchronize()
+                if abs(float(probe[0]) - 1.0) > 1e-6:
+                    self._avg_native = False
+            except Exception:
+                self._avg_native = False
         with torch.no_grad():
             bufs = [module.flat_params()] if self._flat_ok else [p.data for p in module.parameters()]
-            staged = (not self._avg_native) and bufs[0].is_cuda
+            staged = (not self._nccl) and bufs[0].is_cuda
             for b in bufs:
                 if staged:
                     h = b.cpu()
@@ -158,7 +169,7 @@ class FlatDataParallel(nn.Module):
                     p.grad.mul_(1.0 / self.world)
 
     def _allreduce(self, t):
-        if t.is_cuda and not self._avg_native:
+        if t.is_cuda and not self._nccl:
             return _HostStaged(t, self.pg)
         op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
         return dist.all_reduce(t, op=op, group=self.pg, async_op=True)

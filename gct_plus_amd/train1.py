@@ -7,10 +7,12 @@ RANK/LOCAL_RANK/WORLD_SIZE set.  Differences from the reference, all forced by t
 environment and none touching the arithmetic:
   * torch DDP -> gct_plus_amd.dp.FlatDataParallel (RCCL all-reduce of the flat gradient buffer);
   * torch.optim.Adam -> gct_plus_amd.optim.FusedAdam (same state_dict layout);
-  * data: the torchtext/rdkit pipeline (Utils/dataset.py, Model/collate_fn.py) is not part of
-    this build yet; `-synthetic N` trains on synthetic MOSES-shaped
-    token batches, otherwise pre-tokenised `{prepared_folder}/train_tokens.pt` /
-    `test_tokens.pt` (dicts with src/trg[/econds/dconds] tensors) are used.
+  * data: `{prepared_folder}/train[_sca].csv` / `test[_sca].csv` (the reference's prepared CSVs,
+    columns src[, src_scaffold], src_<prop>, trg_<prop>) go through the native tokeniser/collate
+    of gct_plus_amd.data (replaces torchtext Field pickles; vocabularies are built from the
+    training split and stored as {util_folder}/SRC[_sep].json, TRG[_sep].json); `-synthetic N`
+    trains on synthetic MOSES-shaped token batches instead (no dataset can be downloaded here).
+    SMILES randomisation (-randomize_prob, needs rdkit) is not available.
 """
 import argparse
 import logging
@@ -113,20 +115,42 @@ def main(rank, world_size, argv=None):
         LOG.info(f"world size: {world_size}")
     if args.debug:
         args.batch_size = 4
-    n_tr = 32 if (args.debug and args.synthetic) else args.synthetic
-    n_va = 32 if (args.debug and args.synthetic) else (args.synthetic_valid or max(args.synthetic // 10, 0))
-    train = load_tokens(args, "train", n_tr)
-    valid = load_tokens(args, "test", n_va)
     nc = len(args.property_list)
-    if nc != synthetic.n_conds(args.model_type) and args.synthetic:
-        raise ValueError(f"-property_list has {nc} entries but {args.model_type} expects "
-                         f"{synthetic.n_conds(args.model_type)}")
-    train_loader = ShardedLoader(train, args.batch_size, rank, world_size, True, args.seed, device)
-    valid_loader = ShardedLoader(valid, args.batch_size, rank, world_size, False, args.seed, device)
+    sca = args.model_type in ("scavaetf", "pscavaetf")
+    csv_tr = os.path.join(args.prepared_folder, "train_sca.csv" if sca else "train.csv")
+    csv_va = os.path.join(args.prepared_folder, "test_sca.csv" if sca else "test.csv")
+    if args.synthetic == 0 and os.path.exists(csv_tr):
+        # real data: the reference's prepared CSVs (train1.py:68-73) through the native tokeniser
+        import pandas as pd
+        from . import data
+        ftr, fva = pd.read_csv(csv_tr), pd.read_csv(csv_va)
+        if args.debug:
+            ftr, fva = ftr[:32], fva[:32]
+        col = ((ftr["src_scaffold"].astype(str) + "<sep>" + ftr["src"].astype(str)) if sca
+               else ftr["src"].astype(str)).tolist()
+        SRC, TRG, _ = data.get_fields(args.model_type, args.util_folder, col)
+        LOG.info(f"SRC: {SRC.stoi}")
+        LOG.info(f"TRG: {TRG.stoi}")
+        mk = lambda fr, sh: data.SmilesLoader(fr, SRC, TRG, args.model_type, args.property_list,
+                                              args.batch_size, rank, world_size, sh, args.seed, device,
+                                              args.use_scaffold)
+        train_loader, valid_loader = mk(ftr, True), mk(fva, False)
+        src_vocab, trg_vocab = len(SRC), len(TRG)
+        args.sos_id, args.eos_id, args.pad_id = TRG.stoi["<sos>"], TRG.stoi["<eos>"], SRC.stoi["<pad>"]
+    else:
+        n_tr = 32 if (args.debug and args.synthetic) else args.synthetic
+        n_va = 32 if (args.debug and args.synthetic) else (args.synthetic_valid or max(args.synthetic // 10, 0))
+        train = load_tokens(args, "train", n_tr)
+        valid = load_tokens(args, "test", n_va)
+        if nc != synthetic.n_conds(args.model_type) and args.synthetic:
+            raise ValueError(f"-property_list has {nc} entries but {args.model_type} expects "
+                             f"{synthetic.n_conds(args.model_type)}")
+        train_loader = ShardedLoader(train, args.batch_size, rank, world_size, True, args.seed, device)
+        valid_loader = ShardedLoader(valid, args.batch_size, rank, world_size, False, args.seed, device)
+        src_vocab, trg_vocab = synthetic.vocab_sizes(args.model_type)
+        args.sos_id, args.eos_id, args.pad_id = synthetic.SOS_ID, synthetic.EOS_ID, synthetic.PAD_ID
     if rank == 0:
         LOG.info(f"# train / validation loader: {len(train_loader)} / {len(valid_loader)}")
-    src_vocab, trg_vocab = synthetic.vocab_sizes(args.model_type)
-    args.sos_id, args.eos_id, args.pad_id = synthetic.SOS_ID, synthetic.EOS_ID, synthetic.PAD_ID
     if args.start_epoch > 1:
         args.model_path = os.path.join(args.model_folder, f"model_{args.start_epoch-1}.pt")
     model = get_model(args, src_vocab, trg_vocab, rank).cuda()

@@ -188,6 +188,18 @@ int gct_select_token(const float* logits, int V, int64_t* ys, int64_t ld_ys, int
                      int64_t valid_sb, uint8_t* done, float* probs_out, int n, int mode,
                      int64_t pad_id, int64_t eos_id, uint64_t seed, void* stream);
 
+/* ------------------------------------------------ host side: SMILES tokeniser + collate */
+/* Utils/field.py:8-33 moltokenize (the atom-wise regex, findall semantics) as a scanner.
+ * Returns the number of tokens (may exceed max_tokens: call again with a larger buffer). */
+int gct_smiles_tokenize(const char* smi, int with_sep, int32_t* tok_start, int32_t* tok_len,
+                        int max_tokens);
+/* torchtext Field.process as used by Model/collate_fn.py:5-15,104-124: row r of out[n][width] =
+ * [sos] ids(tokens) [eos] pad...; vocab[id] are the token strings, unknown -> unk_id; sos/eos < 0
+ * omit them (SRC field).  Returns the longest row length, <0 on error (row does not fit). */
+int gct_smiles_encode_batch(const char* const* smiles, int n, int with_sep, const char* const* vocab,
+                            int vocab_size, int64_t unk_id, int64_t pad_id, int64_t sos_id,
+                            int64_t eos_id, int64_t* out, int64_t width, int32_t* lengths);
+
 /* ------------------------------------------------------------------ utilities */
 /* dst[(r / rpb)*dst_rpb + dst_off + r % rpb][:] (op)= src[(r / rpb)*src_rpb + src_off + r % rpb][:]
  * row gather/scatter used for the cond2lat concat (Model/vaetf.py:88-91). accumulate: += */

@@ -33,3 +33,24 @@ def test_train1_synthetic_two_epochs_and_resume(tmp_path):
     assert os.path.exists(os.path.join(folder, "model_3.pt"))
     t3 = pd.read_csv(os.path.join(folder, "train_3.csv"), index_col=0)
     assert abs(t3["LR"].iloc[0] - 64 ** -0.5 * 9 * 8000 ** -1.5) < 1e-15  # current_step continues at 8
+
+
+def test_train1_real_smiles_csv(tmp_path):
+    """CSV of SMILES (+scaffold, properties) -> native tokeniser -> one training epoch."""
+    from gct_plus_amd import train1
+    from tests.test_data_pipeline import SMILES
+    rows = [{"src": s, "src_scaffold": "c1ccccc1", "src_logP": 0.1 * i, "trg_logP": 0.1 * i, "src_tPSA": 1.0,
+             "trg_tPSA": 1.0, "src_QED": 0.5, "trg_QED": 0.5} for i, s in enumerate(SMILES * 3)]
+    prep = tmp_path / "prepared"
+    prep.mkdir()
+    pd.DataFrame(rows).to_csv(prep / "train_sca.csv", index=False)
+    pd.DataFrame(rows[:8]).to_csv(prep / "test_sca.csv", index=False)
+    folder = str(tmp_path / "exp")
+    train1.main(0, 1, ("-seed 1 -use_cond2lat -use_scaffold -model_type pscavaetf -property_list logP tPSA QED "
+                       f"-N 2 -d_model 64 -d_ff 128 -H 4 -latent_dim 16 -batch_size 8 -model_folder {folder} "
+                       f"-prepared_folder {prep} -util_folder {tmp_path / 'utils'} -num_epoch 1 "
+                       "-print_every 100").split())
+    assert os.path.exists(os.path.join(folder, "model_1.pt"))
+    assert os.path.exists(tmp_path / "utils" / "TRG_sep.json")
+    t1 = pd.read_csv(os.path.join(folder, "train_1.csv"), index_col=0)
+    assert len(t1) == 6 and t1["LOSS"].notna().all()
