@@ -48,47 +48,75 @@ struct AttnArgs {
   float scale, keep_scale;
   uint32_t thr;
   GctRng rng;
+#ifdef GCT_STAMPS
+  unsigned long long* stamps;
+#endif
 };
+
+#ifdef GCT_STAMPS
+#define ASTAMP(i)                                                                      \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    unsigned long long t__;                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");         \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    seg[i] += t__ - tprev;                                                             \
+    tprev = t__;                                                                       \
+  } while (0)
+#else
+#define ASTAMP(i)
+#endif
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// stage rows [0,L) of a [B][L][ld] head slice into LDS [LP][SD], zero padded, optional scale.
-// Fully unrolled: all global loads of a thread are in flight before the first LDS store.
+// Staging of a [B][L][ld] head slice into LDS [LP][SD] (zero padded, optional scale) is split
+// in two halves so a kernel can put ALL its global loads (q, k, v, dO, mask bytes) in flight
+// before the first LDS store: one exposed HBM/L2 latency per workgroup instead of one per
+// tensor (s_memtime stamps: 14.7k -> ~5k cycles for the forward prologue).
 template <int DK, int NTHR>
-__device__ __forceinline__ void stage(float* dst, const float* src, int64_t ld, int b, int h, int L,
-                                      int LP, float scale, int tid) {
-  constexpr int SD = DK + 4, C = DK / 4;
-  constexpr int ITERS = (16 * NT_MAX * C + NTHR - 1) / NTHR;
+struct Stage {
+  static constexpr int SD = DK + 4, C = DK / 4;
+  static constexpr int ITERS = (16 * NT_MAX * C + NTHR - 1) / NTHR;
   float4 v[ITERS];
+  __device__ __forceinline__ void load(const float* src, int64_t ld, int b, int h, int L, int tid) {
 #pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    const int idx = tid + it * NTHR;
-    const int r = idx / C, c = idx - r * C;
-    v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < L) v[it] = *reinterpret_cast<const float4*>(src + ((int64_t)b * L + r) * ld + h * DK + c * 4);
-  }
-#pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    const int idx = tid + it * NTHR;
-    const int r = idx / C, c = idx - r * C;
-    if (r < LP) {
-      float4 w = v[it];
-      w.x *= scale; w.y *= scale; w.z *= scale; w.w *= scale;
-      *reinterpret_cast<float4*>(dst + r * SD + c * 4) = w;
+    for (int it = 0; it < ITERS; ++it) {
+      const int idx = tid + it * NTHR;
+      const int r = idx / C, c = idx - r * C;
+      v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < L) v[it] = *reinterpret_cast<const float4*>(src + ((int64_t)b * L + r) * ld + h * DK + c * 4);
     }
   }
-}
+  __device__ __forceinline__ void store(float* dst, int LP, float scale, int tid) const {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int idx = tid + it * NTHR;
+      const int r = idx / C, c = idx - r * C;
+      if (r < LP) {
+        float4 w = v[it];
+        w.x *= scale; w.y *= scale; w.z *= scale; w.w *= scale;
+        *reinterpret_cast<float4*>(dst + r * SD + c * 4) = w;
+      }
+    }
+  }
+};
 
 // flags[q][k]: bit2 in range, bit0 not masked, bit1 dropout keep. One Philox call per (q, 4 keys).
 template <int NTHR>
-__device__ __forceinline__ void build_flags(uint32_t* flags32, const AttnArgs& a, int b, int h,
-                                            int LQP, int LKP, int tid) {
-  const int KG = LKP / 4;
-  constexpr int ITERS = (16 * NT_MAX * 4 * NT_MAX + NTHR - 1) / NTHR;
+struct Flags {
+  static constexpr int ITERS = (16 * NT_MAX * 4 * NT_MAX + NTHR - 1) / NTHR;
   uint32_t mv[ITERS];
-  // pass 1: all mask bytes in flight (4 consecutive bytes per item, packed into one word)
+  __device__ __forceinline__ void load(const AttnArgs& a, int b, int LQP, int LKP, int tid);
+  __device__ __forceinline__ void build(uint32_t* flags32, const AttnArgs& a, int b, int h, int LQP,
+                                        int LKP, int tid) const;
+};
+
+template <int NTHR>
+__device__ __forceinline__ void Flags<NTHR>::load(const AttnArgs& a, int b, int LQP, int LKP, int tid) {
+  const int KG = LKP / 4;
+  // all mask bytes in flight (4 consecutive bytes per item, packed into one word)
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     const int idx = tid + it * NTHR;
@@ -103,6 +131,12 @@ __device__ __forceinline__ void build_flags(uint32_t* flags32, const AttnArgs& a
     }
     mv[it] = w;
   }
+}
+
+template <int NTHR>
+__device__ __forceinline__ void Flags<NTHR>::build(uint32_t* flags32, const AttnArgs& a, int b, int h,
+                                                   int LQP, int LKP, int tid) const {
+  const int KG = LKP / 4;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     const int idx = tid + it * NTHR;
@@ -148,6 +182,29 @@ __device__ __forceinline__ void build_tile_maps(const uint32_t* flags32, uint8_t
   }
 }
 
+// Operand fragments for products that contract over the head dimension (S = Q K^T, dP = dO V^T):
+// lane group g owns dk indices [g*DK/4, (g+1)*DK/4), so a lane's whole fragment of one row is
+// NDT consecutive float4 -- NDT ds_read_b128 feed DK/4 MFMAs (any k permutation is legal when
+// both operands use it).  Was: one ds_read_b32 round trip per MFMA (10.8k cycles per 80 MFMAs).
+template <int NDT>
+__device__ __forceinline__ void row_frag(float4 (&f)[NDT], const float* lds, int row, int g) {
+  constexpr int SD = 16 * NDT + 4;
+#pragma unroll
+  for (int j = 0; j < NDT; ++j)
+    f[j] = *reinterpret_cast<const float4*>(lds + row * SD + g * 4 * NDT + 4 * j);
+}
+template <int NDT>
+__device__ __forceinline__ f32x4 dot_frag(const float4 (&a)[NDT], const float4 (&b)[NDT], f32x4 acc) {
+#pragma unroll
+  for (int j = 0; j < NDT; ++j) {
+    acc = mfma16(a[j].x, b[j].x, acc);
+    acc = mfma16(a[j].y, b[j].y, acc);
+    acc = mfma16(a[j].z, b[j].z, acc);
+    acc = mfma16(a[j].w, b[j].w, acc);
+  }
+  return acc;
+}
+
 // bit t set => key tile t must be computed for query tile u
 __device__ __forceinline__ uint32_t tiles_for_q(const uint8_t* rowok, const uint8_t* tile_any, int u,
                                                 int nkt, int c16) {
@@ -176,13 +233,28 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_fwd_kernel(const AttnArgs a)
   uint32_t* flags32 = reinterpret_cast<uint32_t*>(Vs + LKP * SD);
   uint8_t* rowok = reinterpret_cast<uint8_t*>(flags32 + LQP * KG);
   uint8_t* tile_any = rowok + 16 * NT_MAX;
-  stage<DK, FWD_THREADS>(Qs, a.q, a.ldq, b, h, a.Lq, LQP, a.scale, tid);
-  stage<DK, FWD_THREADS>(Ks, a.k, a.ldk, b, h, a.Lk, LKP, 1.0f, tid);
-  stage<DK, FWD_THREADS>(Vs, a.v, a.ldv, b, h, a.Lk, LKP, 1.0f, tid);
-  build_flags<FWD_THREADS>(flags32, a, b, h, LQP, LKP, tid);
+#ifdef GCT_STAMPS
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#endif
+  {
+    Stage<DK, FWD_THREADS> sq, sk, sv;
+    Flags<FWD_THREADS> fl;
+    sq.load(a.q, a.ldq, b, h, a.Lq, tid);
+    sk.load(a.k, a.ldk, b, h, a.Lk, tid);
+    sv.load(a.v, a.ldv, b, h, a.Lk, tid);
+    fl.load(a, b, LQP, LKP, tid);
+    sq.store(Qs, LQP, a.scale, tid);
+    sk.store(Ks, LKP, 1.0f, tid);
+    sv.store(Vs, LKP, 1.0f, tid);
+    ASTAMP(0);  // staging q,k,v
+    fl.build(flags32, a, b, h, LQP, LKP, tid);
+  }
   __syncthreads();
+  ASTAMP(1);  // flags + barrier
   build_tile_maps<FWD_THREADS>(flags32, rowok, tile_any, a.Lq, LQP, LKP, tid);
   __syncthreads();
+  ASTAMP(2);  // tile maps + barrier
 
   for (int u = wave; u < LQP / 16; u += NW) {
     const int q = 16 * u + c16;
@@ -191,13 +263,18 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_fwd_kernel(const AttnArgs a)
 #pragma unroll
     for (int t = 0; t < NT_MAX; ++t) sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // S^T[k][q] = sum_d K[k][d] * Qs[q][d]
-#pragma unroll 4
-    for (int s = 0; s < DK / 4; ++s) {
-      const float bq = Qs[q * SD + 4 * s + g];
+    {
+      float4 bq[NDT];
+      row_frag<NDT>(bq, Qs, q, g);
 #pragma unroll
       for (int t = 0; t < NT_MAX; ++t)
-        if ((use >> t) & 1u) sacc[t] = mfma16(Ks[(16 * t + c16) * SD + 4 * s + g], bq, sacc[t]);
+        if ((use >> t) & 1u) {
+          float4 ak[NDT];
+          row_frag<NDT>(ak, Ks, 16 * t + c16, g);
+          sacc[t] = dot_frag<NDT>(ak, bq, sacc[t]);
+        }
     }
+    ASTAMP(3);  // S = K Q^T
     // mask + softmax over keys (regs x tiles in-lane, then lanes l^16, l^32)
     uint32_t fw[NT_MAX];
     float m = -INFINITY;
@@ -223,7 +300,7 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_fwd_kernel(const AttnArgs a)
       if (t < nkt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = expf(sacc[t][r] - m);
+          const float e = __expf(sacc[t][r] - m);
           sacc[t][r] = e;
           l += e;
         }
@@ -232,7 +309,7 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_fwd_kernel(const AttnArgs a)
     l += __shfl_xor(l, 32, 64);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     const int64_t grow = ((int64_t)b * a.H + h) * a.Lq + q;
-    if (g == 0 && q < a.Lq) a.lse[grow] = m + logf(l);
+    if (g == 0 && q < a.Lq) a.lse[grow] = m + __logf(l);
 #pragma unroll
     for (int t = 0; t < NT_MAX; ++t)
       if (t < nkt) {
@@ -244,6 +321,7 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_fwd_kernel(const AttnArgs a)
           sacc[t][r] = ((fw[t] >> (8 * r)) & 2u) ? p * a.keep_scale : 0.f;
         }
       }
+    ASTAMP(4);  // softmax
     // O^T[d][q] = sum_k V[k][d] * Pdrop^T[k][q]
     f32x4 oacc[NDT];
 #pragma unroll
@@ -266,7 +344,12 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_fwd_kernel(const AttnArgs a)
         *reinterpret_cast<float4*>(orow + 16 * dt) =
             make_float4(oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]);
     }
+    ASTAMP(5);  // P.V + store
   }
+#ifdef GCT_STAMPS
+  if (a.stamps && lane == 0 && blockIdx.x < 64)
+    for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * NW + wave) * 8 + i] = seg[i];
+#endif
 }
 
 // ----------------------------------------------------------------------------- backward
@@ -288,11 +371,20 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
   const uint8_t* flags8 = reinterpret_cast<const uint8_t*>(flags32);
   uint8_t* rowok = reinterpret_cast<uint8_t*>(flags32 + LQP * KG);
   uint8_t* tile_any = rowok + 16 * NT_MAX;
-  stage<DK, BWD_THREADS>(Qs, a.q, a.ldq, b, h, a.Lq, LQP, a.scale, tid);
-  stage<DK, BWD_THREADS>(Ks, a.k, a.ldk, b, h, a.Lk, LKP, 1.0f, tid);
-  stage<DK, BWD_THREADS>(Vs, a.v, a.ldv, b, h, a.Lk, LKP, 1.0f, tid);
-  stage<DK, BWD_THREADS>(dOs, a.dout, a.ldo, b, h, a.Lq, LQP, 1.0f, tid);
-  build_flags<BWD_THREADS>(flags32, a, b, h, LQP, LKP, tid);
+  {
+    Stage<DK, BWD_THREADS> sq, sk, sv, sd;
+    Flags<BWD_THREADS> fl;
+    sq.load(a.q, a.ldq, b, h, a.Lq, tid);
+    sk.load(a.k, a.ldk, b, h, a.Lk, tid);
+    sv.load(a.v, a.ldv, b, h, a.Lk, tid);
+    sd.load(a.dout, a.ldo, b, h, a.Lq, tid);
+    fl.load(a, b, LQP, LKP, tid);
+    sq.store(Qs, LQP, a.scale, tid);
+    sk.store(Ks, LKP, 1.0f, tid);
+    sv.store(Vs, LKP, 1.0f, tid);
+    sd.store(dOs, LQP, 1.0f, tid);
+    fl.build(flags32, a, b, h, LQP, LKP, tid);
+  }
   // delta[q] = sum_d dO[q][d] * O[q][d]  (16 lanes per row)
   for (int r0 = tid >> 4; r0 < LQP; r0 += BWD_THREADS / 16) {
     float acc = 0.f;
@@ -330,15 +422,18 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
         sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         pacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-#pragma unroll 2
-      for (int s = 0; s < DK / 4; ++s) {
-        const float bq = Qs[q * SD + 4 * s + g];
-        const float bd = dOs[q * SD + 4 * s + g];
+      {
+        float4 bq[NDT], bd[NDT];
+        row_frag<NDT>(bq, Qs, q, g);
+        row_frag<NDT>(bd, dOs, q, g);
 #pragma unroll
         for (int t = 0; t < NT_MAX; ++t)
           if ((use >> t) & 1u) {
-            sacc[t] = mfma16(Ks[(16 * t + c16) * SD + 4 * s + g], bq, sacc[t]);  // S^T
-            pacc[t] = mfma16(Vs[(16 * t + c16) * SD + 4 * s + g], bd, pacc[t]);  // dP^T
+            float4 ak[NDT], av[NDT];
+            row_frag<NDT>(ak, Ks, 16 * t + c16, g);
+            row_frag<NDT>(av, Vs, 16 * t + c16, g);
+            sacc[t] = dot_frag<NDT>(ak, bq, sacc[t]);  // S^T
+            pacc[t] = dot_frag<NDT>(av, bd, pacc[t]);  // dP^T
           }
       }
       const float lse = lse_s[q], del = del_s[q];
@@ -349,7 +444,7 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const uint32_t f = (w >> (8 * r)) & 0xffu;
-            const float p = (f & 4u) ? expf(score_of(sacc[t][r], f) - lse) : 0.f;
+            const float p = (f & 4u) ? __expf(score_of(sacc[t][r], f) - lse) : 0.f;
             const float dpd = (f & 2u) ? pacc[t][r] * a.keep_scale : 0.f;
             sacc[t][r] = (f & 1u) ? p * (dpd - del) : 0.f;  // dS^T (masked_fill passes no grad)
           }
@@ -385,22 +480,27 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
         vacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         kacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
+      float4 bk[NDT], bv[NDT];
+      row_frag<NDT>(bk, Ks, k, g);
+      row_frag<NDT>(bv, Vs, k, g);
 #pragma unroll 1
       for (int u = 0; u < nqt; ++u) {
         const bool ok = __all(rowok[16 * u + c16] != 0);
         if (ok && !tile_any[u * NT_MAX + t]) continue;  // fully masked tile: P = dS = 0
         f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, pa = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int s = 0; s < DK / 4; ++s) {
-          sa = mfma16(Qs[(16 * u + c16) * SD + 4 * s + g], Ks[k * SD + 4 * s + g], sa);   // S[q][k]
-          pa = mfma16(dOs[(16 * u + c16) * SD + 4 * s + g], Vs[k * SD + 4 * s + g], pa);  // dP[q][k]
+        {
+          float4 aq[NDT], ad[NDT];
+          row_frag<NDT>(aq, Qs, 16 * u + c16, g);
+          row_frag<NDT>(ad, dOs, 16 * u + c16, g);
+          sa = dot_frag<NDT>(aq, bk, sa);   // S[q][k]
+          pa = dot_frag<NDT>(ad, bv, pa);   // dP[q][k]
         }
         float pd[4], ds[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qq = 16 * u + 4 * g + r;
           const uint32_t f = flags8[qq * LKP + k];
-          const float p = (f & 4u) ? expf(score_of(sa[r], f) - lse_s[qq]) : 0.f;
+          const float p = (f & 4u) ? __expf(score_of(sa[r], f) - lse_s[qq]) : 0.f;
           const float dpd = (f & 2u) ? pa[r] * a.keep_scale : 0.f;
           pd[r] = (f & 2u) ? p * a.keep_scale : 0.f;
           ds[r] = (f & 1u) ? p * (dpd - del_s[qq]) : 0.f;
