@@ -62,6 +62,7 @@ struct GemmArgs {
   float keep_scale;
   uint32_t thr;
   GctRng rng;
+  float* bias_slab;  // wgrad fast path: per-split column sums of dY, [nsplit][M] (nullptr: off)
 #ifdef GCT_STAMPS
   unsigned long long* stamps;  // diagnostic build only (tools/gemm_stamps.hip)
 #endif
@@ -571,8 +572,19 @@ gemm_f32_fast_kernel(const GemmArgs g) {
   unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
 #endif
+  // wgrad only: db[n] = sum_m dY[m][n] falls out of the A tiles already in registers.  Weights
+  // (0/1) instead of branches keep the loop a single basic block; only the tile_n == 0 column of
+  // workgroups contributes, and the duplicated final prefetch is masked out.
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float bw0 = (!A_KC && !B_KC && g.bias_slab && n0 == 0) ? 1.f : 0.f;
+#define GCT_BSUM(w_)                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+    bsum.x = fmaf(w_, ra[i].x, bsum.x); bsum.y = fmaf(w_, ra[i].y, bsum.y);                 \
+    bsum.z = fmaf(w_, ra[i].z, bsum.z); bsum.w = fmaf(w_, ra[i].w, bsum.w);                 \
+  }
   if (nkt > 0) {
     GCT_GLOAD(kbeg);
+    if (!A_KC && !B_KC) { GCT_BSUM(bw0) }
     GCT_LSTORE(0);
   }
   __syncthreads();
@@ -631,6 +643,10 @@ gemm_f32_fast_kernel(const GemmArgs g) {
       GCT_PIN(ra[i]);
       GCT_PIN(rb[i]);
     }
+    if (!A_KC && !B_KC) {
+      const float bw = (kt + 1 < nkt) ? bw0 : 0.f;
+      GCT_BSUM(bw)
+    }
     GCT_LSTORE(cur ^ 1);
     GCT_MFMA16(1);
 #pragma unroll
@@ -647,6 +663,24 @@ gemm_f32_fast_kernel(const GemmArgs g) {
   __syncthreads();  // the speculative fragment read above must finish before LDS is reused
 #undef GCT_FRAGQ
 #undef GCT_MFMA16
+#undef GCT_BSUM
+  if (!A_KC && !B_KC) {
+    if (g.bias_slab && n0 == 0) {            // block-uniform: combine the 8 row groups, fixed order
+      float4* red = reinterpret_cast<float4*>(lds);
+      red[tid] = bsum;
+      __syncthreads();
+      if (tid < 32) {
+        float4 t4 = red[tid];
+        for (int r = 1; r < 8; ++r) {
+          const float4 u = red[r * 32 + tid];
+          t4.x += u.x; t4.y += u.y; t4.z += u.z; t4.w += u.w;
+        }
+        const int64_t col = m0 + tid * 4;
+        if (col + 3 < g.M) *reinterpret_cast<float4*>(g.bias_slab + (int64_t)z * g.M + col) = t4;
+      }
+      __syncthreads();
+    }
+  }
 #undef GCT_GLOAD
 #undef GCT_LSTORE
 #undef GCT_PIN
@@ -698,6 +732,21 @@ gemm_f32_fast_kernel(const GemmArgs g) {
 #endif
 }
 
+// single source of truth for "this launch takes gemm_f32_fast_kernel"
+template <bool A_KC, bool B_KC>
+bool fast_ok(const GemmArgs& g, bool vec) {
+  static const bool no_fast = getenv("GCT_GEMM_NO_FAST") != nullptr;   // A/B switch for benchmarks
+  auto seg_ok = [](int64_t nper, int64_t extent, int64_t gran) { return nper >= extent || nper % gran == 0; };
+  return vec && !no_fast && g.K % BK == 0 && g.ksplit % BK == 0 && g.M >= 4 && g.N >= 4 &&
+         (A_KC ? seg_ok(g.a_nper, g.K, BK) : (seg_ok(g.a_nper, g.M, BM) && g.M % 4 == 0)) &&
+         (B_KC ? seg_ok(g.b_nper, g.N, BN) : (seg_ok(g.b_nper, g.K, BK) && g.N % 4 == 0)) &&
+         g.N % 4 == 0 && g.ldc % 4 == 0 && gct_aligned16(g.c0) && g.c_d1 % 4 == 0 && g.c_d2 % 4 == 0 &&
+         (g.c_nper >= g.N || g.c_nper % 4 == 0) && g.slab_stride % 4 == 0 &&
+         (!g.bias0 || (gct_aligned16(g.bias0) && g.bias_d1 % 4 == 0 && g.bias_d2 % 4 == 0)) &&
+         (!g.resid || gct_aligned16(g.resid)) && (!g.pre || gct_aligned16(g.pre)) &&
+         (!g.pre_in || gct_aligned16(g.pre_in)) && 130 * g.lda < (1ll << 31) && 130 * g.ldb < (1ll << 31);
+}
+
 template <bool A_KC, bool B_KC>
 int launch(const GemmArgs& g, bool vec, hipStream_t st) {
   const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.nsplit;
@@ -707,17 +756,7 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st) {
     return GCT_ERR_ARG;
   }
   dim3 grid((unsigned)tiles), block(256);
-  static const bool no_fast = getenv("GCT_GEMM_NO_FAST") != nullptr;   // A/B switch for benchmarks
-  auto seg_ok = [](int64_t nper, int64_t extent, int64_t gran) { return nper >= extent || nper % gran == 0; };
-  const bool fast =
-      vec && !no_fast && g.K % BK == 0 && g.ksplit % BK == 0 && g.M >= 4 && g.N >= 4 &&
-      (A_KC ? seg_ok(g.a_nper, g.K, BK) : (seg_ok(g.a_nper, g.M, BM) && g.M % 4 == 0)) &&
-      (B_KC ? seg_ok(g.b_nper, g.N, BN) : (seg_ok(g.b_nper, g.K, BK) && g.N % 4 == 0)) &&
-      g.N % 4 == 0 && g.ldc % 4 == 0 && gct_aligned16(g.c0) && g.c_d1 % 4 == 0 && g.c_d2 % 4 == 0 &&
-      (g.c_nper >= g.N || g.c_nper % 4 == 0) && g.slab_stride % 4 == 0 &&
-      (!g.bias0 || (gct_aligned16(g.bias0) && g.bias_d1 % 4 == 0 && g.bias_d2 % 4 == 0)) &&
-      (!g.resid || gct_aligned16(g.resid)) && (!g.pre || gct_aligned16(g.pre)) &&
-      (!g.pre_in || gct_aligned16(g.pre_in)) && 130 * g.lda < (1ll << 31) && 130 * g.ldb < (1ll << 31);
+  const bool fast = fast_ok<A_KC, B_KC>(g, vec);
   if (fast)
     hipLaunchKernelGGL((gemm_f32_fast_kernel<A_KC, B_KC>), grid, block, 0, st, g);
   else if (vec)
@@ -762,7 +801,8 @@ extern "C" int64_t gct_wgrad_ws_bytes(int64_t M, int64_t Ntot, int64_t K) {
   const int s = wgrad_splits(M, Ntot, K);
   const int64_t slab = (int64_t)s * Ntot * K;
   const int64_t cs = gct_colsum_ws_floats(M, Ntot);
-  return (slab > cs ? slab : cs) * (int64_t)sizeof(float) + 256;
+  const int64_t need = slab + 4 + (int64_t)s * Ntot;   // weight slabs + fused bias slabs
+  return (need > cs ? need : cs) * (int64_t)sizeof(float) + 256;
 }
 
 extern "C" int gct_linear_fwd(const float* x, int64_t ldx, int64_t M, int K, const float* w0,
@@ -829,10 +869,6 @@ extern "C" int gct_linear_wgrad(const float* dy0, const float* dy1, const float*
   GCT_CHECK_ARG(lddw == K, "linear_wgrad: dW must be dense [nper][K]");
   hipStream_t st = (hipStream_t)stream;
   const int64_t Ntot = (int64_t)nseg * nper;
-  if (db0) {  // bias gradients first: they share ws with the slabs (stream-ordered)
-    int rc = gct_colsum(dy0, dy1, dy2, lddy, M, nseg, nper, db0, db1, db2, ws, st);
-    if (rc) return rc;
-  }
   const int splits = wgrad_splits(M, Ntot, K);
   GemmArgs g = {};
   g.M = Ntot; g.N = K; g.K = M;  // dW[n][k] = sum_m dY[m][n] X[m][k]
@@ -848,8 +884,23 @@ extern "C" int gct_linear_wgrad(const float* dy0, const float* dy1, const float*
   g.epi = EPI_SLAB;
   const bool vec = al16(dy0) && al16(dy1) && al16(dy2) && al16(x) && (lddy % 4 == 0) &&
                    (ldx % 4 == 0) && (nper % 4 == 0) && (K % 4 == 0);
+  // bias gradients: fused into the GEMM on the fast path (column sums of the A tiles), else a
+  // separate column-sum pass that borrows ws before the slabs are written (stream-ordered)
+  float* bslab = nullptr;
+  if (db0) {
+    if (fast_ok<false, false>(g, vec)) {
+      int64_t off = (int64_t)g.nsplit * g.slab_stride;
+      off = (off + 3) / 4 * 4;
+      bslab = ws + off;                     // [nsplit][Ntot] right behind the weight slabs
+      g.bias_slab = bslab;
+    } else {
+      int rc = gct_colsum(dy0, dy1, dy2, lddy, M, nseg, nper, db0, db1, db2, ws, st);
+      if (rc) return rc;
+    }
+  }
   int rc = launch<false, false>(g, vec, st);
   if (rc) return rc;
-  return gct_reduce_slabs_seg(ws, g.nsplit, g.slab_stride, dw0, dw1, dw2, (int64_t)nper * K,
-                              Ntot * K, st);
+  rc = gct_reduce_slabs_seg(ws, g.nsplit, g.slab_stride, dw0, dw1, dw2, (int64_t)nper * K, Ntot * K, st);
+  if (rc || !bslab) return rc;
+  return gct_reduce_slabs_seg(bslab, g.nsplit, Ntot, db0, db1, db2, nper, Ntot, st);
 }
