@@ -227,8 +227,9 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_fwd_kernel(const AttnArgs a)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
   const int LQP = (a.Lq + 15) & ~15, LKP = (a.Lk + 15) & ~15, nkt = LKP / 16, KG = LKP / 4;
-  float* Qs = smem;
-  float* Ks = Qs + LQP * SD;
+  // Q is only ever a B-operand fragment of its own query row: it is read straight from global
+  // memory into registers (no LDS copy => 50 KB per workgroup at L=80, 3 workgroups per CU)
+  float* Ks = smem;
   float* Vs = Ks + LKP * SD;
   uint32_t* flags32 = reinterpret_cast<uint32_t*>(Vs + LKP * SD);
   uint8_t* rowok = reinterpret_cast<uint8_t*>(flags32 + LQP * KG);
@@ -238,13 +239,11 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_fwd_kernel(const AttnArgs a)
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
 #endif
   {
-    Stage<DK, FWD_THREADS> sq, sk, sv;
+    Stage<DK, FWD_THREADS> sk, sv;
     Flags<FWD_THREADS> fl;
-    sq.load(a.q, a.ldq, b, h, a.Lq, tid);
     sk.load(a.k, a.ldk, b, h, a.Lk, tid);
     sv.load(a.v, a.ldv, b, h, a.Lk, tid);
     fl.load(a, b, LQP, LKP, tid);
-    sq.store(Qs, LQP, a.scale, tid);
     sk.store(Ks, LKP, 1.0f, tid);
     sv.store(Vs, LKP, 1.0f, tid);
     ASTAMP(0);  // staging q,k,v
@@ -256,16 +255,26 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_fwd_kernel(const AttnArgs a)
   __syncthreads();
   ASTAMP(2);  // tile maps + barrier
 
+  // this wave's query fragment (first tile) is requested before the barriers above would let
+  // it be consumed, so its latency overlaps the K/V staging
   for (int u = wave; u < LQP / 16; u += NW) {
     const int q = 16 * u + c16;
+    float4 bq[NDT];
+#pragma unroll
+    for (int j = 0; j < NDT; ++j) {
+      bq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < a.Lq) {
+        bq[j] = *reinterpret_cast<const float4*>(a.q + ((int64_t)b * a.Lq + q) * a.ldq + h * DK +
+                                                 g * 4 * NDT + 4 * j);
+        bq[j].x *= a.scale; bq[j].y *= a.scale; bq[j].z *= a.scale; bq[j].w *= a.scale;
+      }
+    }
     const uint32_t use = tiles_for_q(rowok, tile_any, u, nkt, c16);
     f32x4 sacc[NT_MAX];
 #pragma unroll
     for (int t = 0; t < NT_MAX; ++t) sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // S^T[k][q] = sum_d K[k][d] * Qs[q][d]
     {
-      float4 bq[NDT];
-      row_frag<NDT>(bq, Qs, q, g);
 #pragma unroll
       for (int t = 0; t < NT_MAX; ++t)
         if ((use >> t) & 1u) {
@@ -577,7 +586,7 @@ extern "C" int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
   a.thr = gct_drop_threshold(p); a.keep_scale = 1.0f / (1.0f - p); a.rng = gct_rng_make(seed, site);
   const int LQP = (Lq + 15) & ~15, LKP = (Lk + 15) & ~15, SD = dk + 4;
-  const size_t lds = (size_t)(LQP + 2 * LKP) * SD * 4 + (size_t)LQP * LKP + MAPS_BYTES;
+  const size_t lds = (size_t)(2 * LKP) * SD * 4 + (size_t)LQP * LKP + MAPS_BYTES;
   dim3 grid((unsigned)(B * H)), block(FWD_THREADS);
   hipStream_t st = (hipStream_t)stream;
   static bool f4 = false, f2 = false, f1 = false;

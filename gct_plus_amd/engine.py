@@ -72,6 +72,7 @@ class GradSink:
         return t
 
     def collect(self, params):
+        ops.join_side()      # weight gradients were produced on the side stream (ops.linear_wgrad)
         return tuple(self.out.get(p) for p in params)
 
 
@@ -490,6 +491,7 @@ class LinearFn(torch.autograd.Function):
             dx = _empty(x2.shape[0], x2.shape[1], x2)
             ops.linear_dgrad([dy2], N, x2.shape[0], [w], dx)
             dx = dx.view(ctx.shp)
+        ops.join_side()
         return dx, G.out.get(wp), G.out.get(bp) if bp is not None else None
 
 

@@ -7,6 +7,7 @@ forward/backward passes.  PyTorch is used only for device memory and streams.
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -36,6 +37,50 @@ def _chk(t: torch.Tensor, name: str, dtype=torch.float32):
     if t.dtype != dtype:
         raise _lib.GctError(f"{name}: expected {dtype}, got {t.dtype}")
     return t
+
+
+# ---------------------------------------------------------------------------- side stream
+# Weight-gradient GEMMs are off the critical path of a backward pass (nothing downstream needs
+# dW until the optimiser / all-reduce), so they are launched on a SIDE stream: their workgroups
+# fill the partial last round of the critical-path dgrad GEMMs and the gaps of the small
+# bandwidth kernels.  Correctness bookkeeping (all stream-ordered, no host syncs):
+#   * the side stream waits for an event recorded on the main stream at launch (inputs ready);
+#   * inputs are record_stream()'ed so the caching allocator cannot recycle them early;
+#   * every buffer a pending wgrad READS is remembered (by storage pointer) with the wgrad's
+#     completion event; any main-stream op that WRITES into an existing buffer waits on it first
+#     (the in-place residual-gradient buffer `g` of engine.py is the case that matters);
+#   * join_side() makes the main stream wait for everything (called at the end of each trunk's
+#     backward, before autograd / all-reduce / Adam can touch the gradients).
+# Measured on MI355X (bench.py, B=512): 112.5 ms/step without vs 112.7 ms with the side stream --
+# no gain, so it is OFF by default (GCT_SIDE_STREAM=1 enables it; tests cover both settings).
+SIDE_ENABLED = os.environ.get("GCT_SIDE_STREAM", "0") != "0"
+_SIDE = {}
+_PENDING = {}
+
+
+def _side_stream(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SIDE.get(idx)
+    if st is None:
+        st = torch.cuda.Stream(device=idx)
+        _SIDE[idx] = st
+    return st
+
+
+def _wait_pending(t):
+    """Main stream is about to WRITE into tensor t: wait for side-stream readers of its storage."""
+    if _PENDING and t is not None:
+        ev = _PENDING.pop(t.untyped_storage().data_ptr(), None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+
+def join_side(device=None):
+    if _SIDE:
+        cur = torch.cuda.current_stream()
+        for st in _SIDE.values():
+            cur.wait_stream(st)
+        _PENDING.clear()
 
 
 # ------------------------------------------------------------------------------ workspace
@@ -69,6 +114,7 @@ def norm_fwd(x2d, alpha, bias, eps=1e-6, out=None):
 def norm_bwd(dy, x2d, alpha, mean, rstd, dalpha, dbias, dres=None, out=None, eps=1e-6):
     rows, d = x2d.shape
     dx = torch.empty_like(x2d) if out is None else out
+    _wait_pending(out)
     ws = workspace(_L().gct_rowred_ws_bytes(rows, 2 * d), x2d.device)
     check(_L().gct_norm_bwd(_p(dy), _p(x2d), _p(alpha), _p(mean), _p(rstd), _p(dres), _p(dx),
                             _p(dalpha), _p(dbias), _p(ws), rows, d, eps, _st()), "gct_norm_bwd")
@@ -150,6 +196,7 @@ def linear_dgrad(dys: Sequence[torch.Tensor], lddy: int, M: int, ws_: Sequence[t
     nper, K = ws_[0].shape
     d = _seg3(dys)
     w = _seg3(ws_)
+    _wait_pending(dx)
     with _Timed("gemm_dgrad", 2.0 * M * K * nper * len(ws_)):
         check(_L().gct_linear_dgrad(d[0], d[1], d[2], lddy, M, len(ws_), nper, w[0], w[1], w[2],
                                     ws_[0].stride(0), K, _p(dx), dx.stride(0), depi, _p(pre), p,
@@ -164,16 +211,35 @@ def linear_wgrad(dys: Sequence[torch.Tensor], lddy: int, x2d, dws: Sequence[torc
     d = _seg3(dys)
     dw = _seg3(dws)
     db = _seg3(dbs)
-    ws = workspace(_L().gct_wgrad_ws_bytes(M, nseg * nper, K), x2d.device)
-    with _Timed("gemm_wgrad+bias+reduce", 2.0 * M * K * nper * nseg):
-        check(_L().gct_linear_wgrad(d[0], d[1], d[2], lddy, M, nseg, nper, _p(x2d), x2d.stride(0),
-                                    K, dw[0], dw[1], dw[2], K, db[0], db[1], db[2], _p(ws), _st()),
-              "gct_linear_wgrad")
+
+    def launch():
+        ws = workspace(_L().gct_wgrad_ws_bytes(M, nseg * nper, K), x2d.device)
+        with _Timed("gemm_wgrad+bias+reduce", 2.0 * M * K * nper * nseg):
+            check(_L().gct_linear_wgrad(d[0], d[1], d[2], lddy, M, nseg, nper, _p(x2d), x2d.stride(0),
+                                        K, dw[0], dw[1], dw[2], K, db[0], db[1], db[2], _p(ws), _st()),
+                  "gct_linear_wgrad")
+
+    if not SIDE_ENABLED or torch.cuda.is_current_stream_capturing():
+        launch()
+        return
+    main = torch.cuda.current_stream()
+    side = _side_stream(x2d.device)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    side.wait_event(ready)
+    with torch.cuda.stream(side):
+        launch()
+        done = torch.cuda.Event()
+        done.record(side)
+    for t in list(dys) + [x2d]:
+        t.record_stream(side)
+        _PENDING[t.untyped_storage().data_ptr()] = done
 
 
 def dropout_bwd(dout2d, p, seed, site, out=None):
     rows, cols = dout2d.shape
     dy = torch.empty_like(dout2d) if out is None else out
+    _wait_pending(out)
     check(_L().gct_dropout_bwd(_p(dout2d), _p(dy), rows, cols, p, seed, site, _st()),
           "gct_dropout_bwd")
     return dy

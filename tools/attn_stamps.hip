@@ -22,7 +22,7 @@ int main() {
     const float p = variant ? 0.1f : 0.0f;
     a.thr = gct_drop_threshold(p); a.keep_scale = 1.f / (1.f - p); a.rng = gct_rng_make(1, 1);
     a.stamps = st;
-    const size_t lds = (size_t)(80 + 160) * 68 * 4 + 80 * 80 + MAPS_BYTES;
+    const size_t lds = (size_t)(160) * 68 * 4 + 80 * 80 + MAPS_BYTES;
     hipFuncSetAttribute((const void*)attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (int rep = 0; rep < 3; ++rep) {
       hipMemset(st, 0, 64 * 8 * 8 * 8);
