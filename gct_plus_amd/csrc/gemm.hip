@@ -732,6 +732,109 @@ gemm_f32_fast_kernel(const GemmArgs g) {
 #endif
 }
 
+
+// =====================================================================================
+// SKINNY-M forward kernel (KV-cached decode: M = batch rows per step = 512): 64x64 tiles, 4 waves
+// of one 32x32 MFMA tile each, 32 KB LDS => 4-5 workgroups per CU and 4x as many tiles as the
+// 128x128 kernel, which fills only 16-64 of the 256 CUs at M = 512.  Same operand layout
+// (x [M][K], w [N][K]), same epilogue (FastEpi), simple two-buffer pipeline.
+// =====================================================================================
+__global__ __launch_bounds__(256) void gemm_f32_small_kernel(const GemmArgs g) {
+  constexpr int SB = 64, STILE = SB * BK;  // 2048 floats per operand tile
+  __shared__ __attribute__((aligned(16))) float lds[4 * STILE];  // A0 B0 A1 B1 : 32 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const unsigned tiles_n = (unsigned)((g.N + SB - 1) / SB);
+  const unsigned lid = gct_xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t m0 = (int64_t)(lid / tiles_n) * SB, n0 = (int64_t)(lid % tiles_n) * SB;
+
+  uint32_t offa[2], offb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int64_t r = (tid >> 3) + 32 * i;
+    int64_t ra_ = r, rb_ = r;
+    if (m0 + ra_ > g.M - 1) ra_ = g.M - 1 - m0;
+    if (n0 + rb_ > g.N - 1) rb_ = g.N - 1 - n0;
+    offa[i] = (uint32_t)(ra_ * g.lda + (tid & 7) * 4);
+    offb[i] = (uint32_t)(rb_ * g.ldb + (tid & 7) * 4);
+  }
+  const bool g1 = n0 >= g.b_nper, g2 = n0 >= 2 * g.b_nper;   // the 64-row weight tile lies in one segment
+  const float* bbase0 = g.b.p0 + (g2 ? g.b.d2 : (g1 ? g.b.d1 : 0)) +
+                        (n0 - (g2 ? 2 * g.b_nper : (g1 ? g.b_nper : 0))) * g.ldb;
+  const float* abase0 = g.a.p0 + m0 * g.lda;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 ra[2], rb[2];
+  auto gload = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ra[i] = *reinterpret_cast<const float4*>(abase0 + k0 + offa[i]);
+      rb[i] = *reinterpret_cast<const float4*>(bbase0 + k0 + offb[i]);
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* la = lds + buf * 2 * STILE;
+    float* lb = la + STILE;
+    const int c8 = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      const int chunk = c8 ^ ((row >> 1) & 7);
+      *reinterpret_cast<float4*>(la + row * BK + chunk * 4) = ra[i];
+      *reinterpret_cast<float4*>(lb + row * BK + chunk * 4) = rb[i];
+    }
+  };
+  const int64_t nkt = g.K / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int h = lane >> 5;
+  for (int64_t kt = 0; kt < nkt; ++kt) {
+    const int cur = (int)(kt & 1);
+    if (kt + 1 < nkt) gload((kt + 1) * BK);
+    const float* la = lds + cur * 2 * STILE;
+    const float* lb = la + STILE;
+    const int rowa = wm + (lane & 31), rowb = wn + (lane & 31);
+    const int swa = (rowa >> 1) & 7, swb = (rowb >> 1) & 7;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 a4 = *reinterpret_cast<const float4*>(la + rowa * BK + (((h * 4 + c) ^ swa) * 4));
+      const float4 b4 = *reinterpret_cast<const float4*>(lb + rowb * BK + (((h * 4 + c) ^ swb) * 4));
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+    if (kt + 1 < nkt) lstore(cur ^ 1);
+    __syncthreads();
+  }
+  // epilogue: per-wave 32x32 transpose through LDS, 4x4 patch per lane
+  float* stg = lds + wave * 1024;
+  {
+    const int c32 = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + c32] = acc[r];
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  const FastEpi ep{g};
+  const int rg = lane >> 3, c4 = lane & 7;           // 8 row groups x 8 column chunks
+  const int64_t row0 = m0 + wm + rg * 4, col0 = n0 + wn + c4 * 4;
+  if (row0 < g.M && col0 < g.N) {
+    float4 v[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) v[rr] = *reinterpret_cast<const float4*>(stg + (rg * 4 + rr) * 32 + c4 * 4);
+    const bool q1 = col0 >= g.c_nper, q2 = col0 >= 2 * g.c_nper;
+    const int64_t cloc = col0 - (q2 ? 2 * g.c_nper : (q1 ? g.c_nper : 0));
+    float* cbase = g.c0 + (q2 ? g.c_d2 : (q1 ? g.c_d1 : 0));
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias0) bias = *reinterpret_cast<const float4*>(g.bias0 + (q2 ? g.bias_d2 : (q1 ? g.bias_d1 : 0)) + cloc);
+    ep.apply(v, row0, col0, cbase, cloc, bias);
+  }
+}
+
 // single source of truth for "this launch takes gemm_f32_fast_kernel"
 template <bool A_KC, bool B_KC>
 bool fast_ok(const GemmArgs& g, bool vec) {
@@ -757,6 +860,14 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st) {
   }
   dim3 grid((unsigned)tiles), block(256);
   const bool fast = fast_ok<A_KC, B_KC>(g, vec);
+  // skinny M (decode steps): 64x64 tiles when the 128x128 grid would leave most CUs idle
+  if (fast && A_KC && B_KC && g.nsplit == 1 && tiles < 192 && g.epi < EPI_D0 &&
+      (g.b_nper >= g.N || g.b_nper % 64 == 0)) {
+    const int64_t st_ = ((g.M + 63) / 64) * ((g.N + 63) / 64);
+    hipLaunchKernelGGL(gemm_f32_small_kernel, dim3((unsigned)st_), dim3(256), 0, st, g);
+    GCT_LAUNCH_CHECK("gemm_f32_small");
+    return GCT_OK;
+  }
   if (fast)
     hipLaunchKernelGGL((gemm_f32_fast_kernel<A_KC, B_KC>), grid, block, 0, st, g);
   else if (vec)
