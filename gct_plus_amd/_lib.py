@@ -26,6 +26,9 @@ SIGNATURES = {
     "gct_embed_pe_bwd": (I32, [P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, U64, U32, P]),
     "gct_linear_fwd": (I32, [P, I64, I64, I32, P, P, P, I64, P, P, P, I32, I32, P, P, P, I64,
                              I32, P, P, F32, U64, U32, P]),
+    "gct_linear_fwd_ws_bytes": (I64, [I64, I32, I32]),
+    "gct_linear_fwd_ws": (I32, [P, I64, I64, I32, P, P, P, I64, P, P, P, I32, I32, P, P, P, I64,
+                                I32, P, P, F32, U64, U32, P, P]),
     "gct_linear_dgrad": (I32, [P, P, P, I64, I64, I32, I32, P, P, P, I64, I32, P, I64, I32, P,
                                F32, U64, U32, P]),
     "gct_linear_wgrad": (I32, [P, P, P, I64, I64, I32, I32, P, I64, I32, P, P, P, I64, P, P, P,

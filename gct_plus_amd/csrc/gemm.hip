@@ -745,8 +745,12 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const unsigned tiles_n = (unsigned)((g.N + SB - 1) / SB);
-  const unsigned lid = gct_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned tiles_m = (unsigned)((g.M + SB - 1) / SB);
+  const unsigned lid0 = gct_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned z = lid0 / (tiles_m * tiles_n), lid = lid0 - z * (tiles_m * tiles_n);
   const int64_t m0 = (int64_t)(lid / tiles_n) * SB, n0 = (int64_t)(lid % tiles_n) * SB;
+  const int64_t kbeg = (int64_t)z * g.ksplit;
+  const int64_t kend = (kbeg + g.ksplit < g.K) ? kbeg + g.ksplit : g.K;
 
   uint32_t offa[2], offb[2];
 #pragma unroll
@@ -786,14 +790,14 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const GemmArgs g) {
       *reinterpret_cast<float4*>(lb + row * BK + chunk * 4) = rb[i];
     }
   };
-  const int64_t nkt = g.K / BK;
-  gload(0);
+  const int64_t nkt = (kend - kbeg) / BK;
+  gload(kbeg);
   lstore(0);
   __syncthreads();
   const int h = lane >> 5;
   for (int64_t kt = 0; kt < nkt; ++kt) {
     const int cur = (int)(kt & 1);
-    if (kt + 1 < nkt) gload((kt + 1) * BK);
+    if (kt + 1 < nkt) gload(kbeg + (kt + 1) * BK);
     const float* la = lds + cur * 2 * STILE;
     const float* lb = la + STILE;
     const int rowa = wm + (lane & 31), rowb = wn + (lane & 31);
@@ -826,6 +830,13 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const GemmArgs g) {
     float4 v[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) v[rr] = *reinterpret_cast<const float4*>(stg + (rg * 4 + rr) * 32 + c4 * 4);
+    if (g.epi == EPI_SLAB) {                 // split-K partial: raw sums, dense [M][N] slab z
+      float* sl = g.c0 + (int64_t)z * g.slab_stride;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        if (row0 + rr < g.M) *reinterpret_cast<float4*>(sl + (row0 + rr) * g.N + col0) = v[rr];
+      return;
+    }
     const bool q1 = col0 >= g.c_nper, q2 = col0 >= 2 * g.c_nper;
     const int64_t cloc = col0 - (q2 ? 2 * g.c_nper : (q1 ? g.c_nper : 0));
     float* cbase = g.c0 + (q2 ? g.c_d2 : (q1 ? g.c_d1 : 0));
@@ -833,6 +844,36 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const GemmArgs g) {
     if (g.bias0) bias = *reinterpret_cast<const float4*>(g.bias0 + (q2 ? g.bias_d2 : (q1 ? g.bias_d1 : 0)) + cloc);
     ep.apply(v, row0, col0, cbase, cloc, bias);
   }
+}
+
+
+// split-K tail of the skinny-M path: out = epilogue(sum_s slab[s] + bias ...), one 4x4 patch per
+// thread, float4 everywhere, same FastEpi as the GEMM kernels.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs g, const float* slabs,
+                                                              int nslab, int64_t slab_stride) {
+  const int64_t pc = g.N / 4, pr = (g.M + 3) / 4;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= pc * pr) return;
+  const int64_t row0 = (idx / pc) * 4, col0 = (idx % pc) * 4;
+  float4 v[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    v[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + rr < g.M) {
+      const float* p = slabs + (row0 + rr) * g.N + col0;
+      for (int s = 0; s < nslab; ++s) {
+        const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)s * slab_stride);
+        v[rr].x += t.x; v[rr].y += t.y; v[rr].z += t.z; v[rr].w += t.w;
+      }
+    }
+  }
+  const bool q1 = col0 >= g.c_nper, q2 = col0 >= 2 * g.c_nper;
+  const int64_t cloc = col0 - (q2 ? 2 * g.c_nper : (q1 ? g.c_nper : 0));
+  float* cbase = g.c0 + (q2 ? g.c_d2 : (q1 ? g.c_d1 : 0));
+  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.bias0) bias = *reinterpret_cast<const float4*>(g.bias0 + (q2 ? g.bias_d2 : (q1 ? g.bias_d1 : 0)) + cloc);
+  const FastEpi ep{g};
+  ep.apply(v, row0, col0, cbase, cloc, bias);
 }
 
 // single source of truth for "this launch takes gemm_f32_fast_kernel"
@@ -851,7 +892,7 @@ bool fast_ok(const GemmArgs& g, bool vec) {
 }
 
 template <bool A_KC, bool B_KC>
-int launch(const GemmArgs& g, bool vec, hipStream_t st) {
+int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullptr) {
   const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.nsplit;
   if (tiles <= 0) return GCT_OK;
   if (tiles > INT_MAX) {
@@ -864,8 +905,30 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st) {
   if (fast && A_KC && B_KC && g.nsplit == 1 && tiles < 192 && g.epi < EPI_D0 &&
       (g.b_nper >= g.N || g.b_nper % 64 == 0)) {
     const int64_t st_ = ((g.M + 63) / 64) * ((g.N + 63) / 64);
-    hipLaunchKernelGGL(gemm_f32_small_kernel, dim3((unsigned)st_), dim3(256), 0, st, g);
-    GCT_LAUNCH_CHECK("gemm_f32_small");
+    const int64_t nkt = g.K / BK;
+    int64_t ns = 1;
+    if (skinny_ws && gct_aligned16(skinny_ws)) {      // split-K: >= 4 K-tiles per split, ~768 blocks
+      ns = 768 / st_;
+      if (ns > nkt / 4) ns = nkt / 4;
+      if (ns < 1) ns = 1;
+    }
+    if (ns <= 1) {
+      hipLaunchKernelGGL(gemm_f32_small_kernel, dim3((unsigned)st_), dim3(256), 0, st, g);
+      GCT_LAUNCH_CHECK("gemm_f32_small");
+      return GCT_OK;
+    }
+    GemmArgs p = g;                                   // pass 1: raw partial sums into slabs
+    p.ksplit = ((nkt + ns - 1) / ns) * BK;
+    p.nsplit = (int)((g.K + p.ksplit - 1) / p.ksplit);
+    p.epi = EPI_SLAB;
+    p.c0 = skinny_ws;
+    p.slab_stride = g.M * g.N;
+    hipLaunchKernelGGL(gemm_f32_small_kernel, dim3((unsigned)(st_ * p.nsplit)), dim3(256), 0, st, p);
+    GCT_LAUNCH_CHECK("gemm_f32_small(split-K)");
+    const int64_t patches = ((g.M + 3) / 4) * (g.N / 4);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((patches + 255) / 256)), dim3(256), 0, st,
+                       g, (const float*)skinny_ws, p.nsplit, p.slab_stride);
+    GCT_LAUNCH_CHECK("splitk_epilogue");
     return GCT_OK;
   }
   if (fast)
@@ -916,11 +979,12 @@ extern "C" int64_t gct_wgrad_ws_bytes(int64_t M, int64_t Ntot, int64_t K) {
   return (need > cs ? need : cs) * (int64_t)sizeof(float) + 256;
 }
 
-extern "C" int gct_linear_fwd(const float* x, int64_t ldx, int64_t M, int K, const float* w0,
-                              const float* w1, const float* w2, int64_t ldw, const float* b0,
-                              const float* b1, const float* b2, int nseg, int nper, float* y0,
-                              float* y1, float* y2, int64_t ldy, int epi, const float* resid,
-                              float* pre, float p, uint64_t seed, uint32_t site, void* stream) {
+static int linear_fwd_impl(const float* x, int64_t ldx, int64_t M, int K, const float* w0,
+                           const float* w1, const float* w2, int64_t ldw, const float* b0,
+                           const float* b1, const float* b2, int nseg, int nper, float* y0,
+                           float* y1, float* y2, int64_t ldy, int epi, const float* resid,
+                           float* pre, float p, uint64_t seed, uint32_t site, float* ws,
+                           void* stream) {
   GCT_CHECK_ARG(x && w0 && y0 && M >= 0 && K > 0 && nseg >= 1 && nseg <= 3 && nper > 0,
                 "linear_fwd: bad args");
   GCT_CHECK_ARG(nseg < 2 || (w1 && y1), "linear_fwd: missing segment 1");
@@ -942,7 +1006,32 @@ extern "C" int gct_linear_fwd(const float* x, int64_t ldx, int64_t M, int K, con
   g.thr = gct_drop_threshold(p); g.keep_scale = 1.0f / (1.0f - p); g.rng = gct_rng_make(seed, site);
   const bool vec = al16(x) && al16(w0) && al16(w1) && al16(w2) && (ldx % 4 == 0) &&
                    (ldw % 4 == 0) && (K % 4 == 0);
-  return launch<true, true>(g, vec, (hipStream_t)stream);
+  return launch<true, true>(g, vec, (hipStream_t)stream, ws);
+}
+
+extern "C" int gct_linear_fwd(const float* x, int64_t ldx, int64_t M, int K, const float* w0,
+                              const float* w1, const float* w2, int64_t ldw, const float* b0,
+                              const float* b1, const float* b2, int nseg, int nper, float* y0,
+                              float* y1, float* y2, int64_t ldy, int epi, const float* resid,
+                              float* pre, float p, uint64_t seed, uint32_t site, void* stream) {
+  return linear_fwd_impl(x, ldx, M, K, w0, w1, w2, ldw, b0, b1, b2, nseg, nper, y0, y1, y2, ldy, epi,
+                         resid, pre, p, seed, site, nullptr, stream);
+}
+
+extern "C" int gct_linear_fwd_ws(const float* x, int64_t ldx, int64_t M, int K, const float* w0,
+                                 const float* w1, const float* w2, int64_t ldw, const float* b0,
+                                 const float* b1, const float* b2, int nseg, int nper, float* y0,
+                                 float* y1, float* y2, int64_t ldy, int epi, const float* resid,
+                                 float* pre, float p, uint64_t seed, uint32_t site, float* ws,
+                                 void* stream) {
+  return linear_fwd_impl(x, ldx, M, K, w0, w1, w2, ldw, b0, b1, b2, nseg, nper, y0, y1, y2, ldy, epi,
+                         resid, pre, p, seed, site, ws, stream);
+}
+
+extern "C" int64_t gct_linear_fwd_ws_bytes(int64_t M, int K, int Ntot) {
+  // worst case: K/128 slabs of [M][Ntot]; only used for skinny M, so this stays small
+  const int64_t ns = K / (4 * BK) > 0 ? K / (4 * BK) : 1;
+  return ns * M * Ntot * (int64_t)sizeof(float) + 256;
 }
 
 extern "C" int gct_linear_dgrad(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,

@@ -79,6 +79,9 @@ class KVDecoder:
         # per-step scratch (fixed addresses => graph friendly)
         dff = dec.layers[0].ff.linear_1.weight.shape[0]
         V = self.model.out.weight.shape[0]
+        wsb = max(ops._L().gct_linear_fwd_ws_bytes(n, dff, d), ops._L().gct_linear_fwd_ws_bytes(n, d, 3 * d),
+                  ops._L().gct_linear_fwd_ws_bytes(n, d, dff))
+        self.ws = torch.empty(wsb // 4 + 64, device=dev)           # split-K slabs of the skinny GEMMs
         f = lambda *s: torch.empty(*s, device=dev)
         self.buf = dict(x2=f(n, d), o=f(n, d), xa=f(n, d), q2=f(n, d), o2=f(n, d), xb=f(n, d),
                         pre=f(n, dff), hdn=f(n, dff), xc=[f(n, d), f(n, d)], y=f(n, d),
@@ -97,24 +100,24 @@ class KVDecoder:
             ops.norm_fwd(x, layer.norm_1.alpha, layer.norm_1.bias, layer.norm_1.eps, out=B["x2"])
             qs, ks, vs = self.qc[li][:, pos], self.kc[li][:, pos], self.vc[li][:, pos]
             ops.linear_fwd(B["x2"], [a1.q_linear.weight, a1.k_linear.weight, a1.v_linear.weight],
-                           [a1.q_linear.bias, a1.k_linear.bias, a1.v_linear.bias], [qs, ks, vs], T * d)
+                           [a1.q_linear.bias, a1.k_linear.bias, a1.v_linear.bias], [qs, ks, vs], T * d, splitk_ws=self.ws)
             ops.attn_decode(qs, T * d, self.kc[li], self.vc[li], d, T * d, self.valid, T, B["o"], n,
                             self.H, pos + 1, self.dk)
             ops.linear_fwd(B["o"], [a1.out.weight], [a1.out.bias], [B["xa"]], d,
-                           epi=ops.EPI_DROP_RESID, resid=x)
+                           epi=ops.EPI_DROP_RESID, resid=x, splitk_ws=self.ws)
             ops.norm_fwd(B["xa"], layer.norm_2.alpha, layer.norm_2.bias, layer.norm_2.eps, out=B["x2"])
-            ops.linear_fwd(B["x2"], [a2.q_linear.weight], [a2.q_linear.bias], [B["q2"]], d)
+            ops.linear_fwd(B["x2"], [a2.q_linear.weight], [a2.q_linear.bias], [B["q2"]], d, splitk_ws=self.ws)
             kv = self.cross_kv[li]
             ops.attn_decode(B["q2"], d, kv, kv[:, d:], 2 * d, self.Lk * 2 * d, self.src_valid, self.Lk,
                             B["o2"], n, self.H, self.Lk, self.dk)
             ops.linear_fwd(B["o2"], [a2.out.weight], [a2.out.bias], [B["xb"]], d,
-                           epi=ops.EPI_DROP_RESID, resid=B["xa"])
+                           epi=ops.EPI_DROP_RESID, resid=B["xa"], splitk_ws=self.ws)
             ops.norm_fwd(B["xb"], layer.norm_3.alpha, layer.norm_3.bias, layer.norm_3.eps, out=B["x2"])
             ops.linear_fwd(B["x2"], [ff.linear_1.weight], [ff.linear_1.bias], [B["hdn"]],
-                           B["hdn"].shape[1], epi=ops.EPI_GELU_DROP, pre=B["pre"])
+                           B["hdn"].shape[1], epi=ops.EPI_GELU_DROP, pre=B["pre"], splitk_ws=self.ws)
             xc = B["xc"][li & 1]
             ops.linear_fwd(B["hdn"], [ff.linear_2.weight], [ff.linear_2.bias], [xc], d,
-                           epi=ops.EPI_DROP_RESID, resid=B["xb"])
+                           epi=ops.EPI_DROP_RESID, resid=B["xb"], splitk_ws=self.ws)
             x = xc
         ops.norm_fwd(x, dec.norm.alpha, dec.norm.bias, dec.norm.eps, out=B["y"])
         out = self.model.out

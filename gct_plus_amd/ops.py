@@ -177,7 +177,7 @@ def _seg3(ts: Sequence[Optional[torch.Tensor]]):
 
 def linear_fwd(x2d, ws_: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Tensor]],
                outs: Sequence[torch.Tensor], ldy: int, epi=EPI_BIAS, resid=None, pre=None,
-               p=0.0, seed=0, site=0):
+               p=0.0, seed=0, site=0, splitk_ws: Optional[torch.Tensor] = None):
     """y_s = epi(x @ w_s^T + b_s); outs are (views of) pre-allocated [M, nper] blocks with
     leading dimension ldy."""
     M, K = x2d.shape
@@ -185,6 +185,12 @@ def linear_fwd(x2d, ws_: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Ten
     w = _seg3(ws_)
     b = _seg3(bs)
     y = _seg3(outs)
+    if splitk_ws is not None:      # skinny-M path (decode): split-K through the workspace
+        check(_L().gct_linear_fwd_ws(_p(x2d), x2d.stride(0), M, K, w[0], w[1], w[2], ws_[0].stride(0),
+                                     b[0], b[1], b[2], len(ws_), nper, y[0], y[1], y[2], ldy, epi,
+                                     _p(resid), _p(pre), p, seed, site, _p(splitk_ws), _st()),
+              "gct_linear_fwd_ws")
+        return
     with _Timed("gemm_fwd", 2.0 * M * K * nper * len(ws_)):
         check(_L().gct_linear_fwd(_p(x2d), x2d.stride(0), M, K, w[0], w[1], w[2], ws_[0].stride(0),
                                   b[0], b[1], b[2], len(ws_), nper, y[0], y[1], y[2], ldy, epi,

@@ -92,6 +92,17 @@ int gct_linear_fwd(const float* x, int64_t ldx, int64_t M, int K,
                    int epi, const float* resid, float* pre, float p, uint64_t seed, uint32_t site,
                    void* stream);
 
+/* Same contract with a caller-provided workspace (>= gct_linear_fwd_ws_bytes): lets skinny-M
+ * shapes (decode steps, M = batch rows) run split-K with a fused reduce+epilogue pass so all CUs
+ * get work; identical results up to fp32 summation order. */
+int64_t gct_linear_fwd_ws_bytes(int64_t M, int K, int Ntot);
+int gct_linear_fwd_ws(const float* x, int64_t ldx, int64_t M, int K,
+                      const float* w0, const float* w1, const float* w2, int64_t ldw,
+                      const float* b0, const float* b1, const float* b2, int nseg, int nper,
+                      float* y0, float* y1, float* y2, int64_t ldy,
+                      int epi, const float* resid, float* pre, float p, uint64_t seed, uint32_t site,
+                      float* ws, void* stream);
+
 /* dx[m][k] (op)= sum_s sum_n dy_s[m][n] * w_s[n][k]
  *   GCT_DEPI_STORE / GCT_DEPI_ACCUM (dx += ...) /
  *   GCT_DEPI_GELU_BWD : dx = acc * gelu'(pre[m][k]) * dropmask(site)/(1-p)   (through FFN-1 act.) */
