@@ -380,6 +380,10 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
   const uint8_t* flags8 = reinterpret_cast<const uint8_t*>(flags32);
   uint8_t* rowok = reinterpret_cast<uint8_t*>(flags32 + LQP * KG);
   uint8_t* tile_any = rowok + 16 * NT_MAX;
+#ifdef GCT_STAMPS
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#endif
   {
     Stage<DK, BWD_THREADS> sq, sk, sv, sd;
     Flags<BWD_THREADS> fl;
@@ -394,6 +398,7 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
     sd.store(dOs, LQP, 1.0f, tid);
     fl.build(flags32, a, b, h, LQP, LKP, tid);
   }
+  ASTAMP(0);  // staging + flags
   // delta[q] = sum_d dO[q][d] * O[q][d]  (16 lanes per row)
   for (int r0 = tid >> 4; r0 < LQP; r0 += BWD_THREADS / 16) {
     float acc = 0.f;
@@ -416,8 +421,10 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
     }
   }
   __syncthreads();
+  ASTAMP(1);  // delta + barrier
   build_tile_maps<BWD_THREADS>(flags32, rowok, tile_any, a.Lq, LQP, LKP, tid);
   __syncthreads();
+  ASTAMP(2);  // maps + barrier
 
   // work units 0..nqt-1 = pass A (query tiles), nqt..nqt+nkt-1 = pass B (key tiles)
   for (int unit = wave; unit < nqt + nkt; unit += NW) {
@@ -537,7 +544,12 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
         }
       }
     }
+    ASTAMP(3);  // unit (pass A or pass B)
   }
+#ifdef GCT_STAMPS
+  if (a.stamps && lane == 0 && blockIdx.x < 64)
+    for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * NW + wave) * 8 + i] = seg[i];
+#endif
 }
 
 template <typename K>

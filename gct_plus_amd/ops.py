@@ -151,6 +151,7 @@ def embed_pe_bwd(dout, tok, dtable, dcond, n_c, scale, p, seed, site, d=None):
 # dict, every gct_linear_* launch is bracketed by HIP events on the launch stream and logged as
 # (kernel kind, flops, start event, end event).  Off (None) in normal operation.
 PROFILE = None
+PROFILE_KINDS = None      # None: every GEMM kind; else a set such as {"gemm_fwd"}
 
 
 class _Timed:
@@ -158,14 +159,15 @@ class _Timed:
         self.kind, self.flops = kind, flops
 
     def __enter__(self):
-        if PROFILE is not None:
+        self.on = PROFILE is not None and (PROFILE_KINDS is None or self.kind in PROFILE_KINDS)
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
         return self
 
     def __exit__(self, *a):
-        if PROFILE is not None:
+        if self.on:
             self.e1.record()
             PROFILE.setdefault(self.kind, []).append((self.flops, self.e0, self.e1))
 

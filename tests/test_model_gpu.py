@@ -338,3 +338,23 @@ def test_get_attn_and_submodules():
         layer.ff.linear_2.weight, layer.ff.linear_2.bias)
     assert torch.allclose(y, ref, atol=1e-4)
     assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+def test_side_stream_wgrad_gives_identical_gradients(golden_dir, monkeypatch):
+    """GCT_SIDE_STREAM=1 (weight-gradient GEMMs on a second stream) must not change a single bit."""
+    from gct_plus_amd import ops
+    fx = torch.load(os.path.join(golden_dir, "g2_pscavaetf.pt"), weights_only=True)
+    grads = []
+    for side in (False, True):
+        monkeypatch.setattr(ops, "SIDE_ENABLED", side)
+        model = build("pscavaetf").train()
+        set_eps(model, fx["eps"])
+        for _ in range(3):                                   # several backward passes, buffers recycled
+            for p in model.parameters():
+                p.grad = None
+            run_fwd_loss(model, "pscavaetf", fx["batch"], fx["beta"])[5].backward()
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys()
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k

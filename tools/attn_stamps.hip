@@ -7,7 +7,7 @@ int main() {
   const int B = 512, H = 8, L = 80, dk = 64, d = H * dk;
   float *qkv, *o, *lse; uint8_t* mask; unsigned long long* st;
   hipMalloc(&qkv, (size_t)B * L * 3 * d * 4); hipMalloc(&o, (size_t)B * L * d * 4); hipMalloc(&lse, B * H * L * 4);
-  hipMalloc(&mask, B * L); hipMalloc(&st, 64 * 8 * 8 * 8);
+  hipMalloc(&mask, B * L); hipMalloc(&st, 64 * 12 * 8 * 8);
   std::vector<float> h((size_t)B * L * 3 * d);
   for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
   hipMemcpy(qkv, h.data(), h.size() * 4, hipMemcpyHostToDevice);
@@ -39,6 +39,34 @@ int main() {
       double tot = 0; for (int i = 0; i < 6; ++i) tot += seg[i];
       printf(" wave %d lifetime %.0f cycles:", w, tot);
       for (int i = 0; i < 6; ++i) printf("  %s %.0f", nm[i], seg[i]);
+      printf("\n");
+    }
+  }
+  {  // backward
+    float *dqkv, *dout; hipMalloc(&dqkv, (size_t)B * L * 3 * d * 4); hipMalloc(&dout, (size_t)B * L * d * 4);
+    hipMemcpy(dout, h.data(), (size_t)B * L * d * 4, hipMemcpyHostToDevice);
+    AttnArgs a = {};
+    a.q = qkv; a.k = qkv + d; a.v = qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
+    a.mask = mask; a.mask_sb = L; a.mask_sq = 0; a.o_in = o; a.dout = dout; a.ldo = d; a.lse_in = lse;
+    a.dq = dqkv; a.dk = dqkv + d; a.dv = dqkv + 2 * d; a.lddq = a.lddk = a.lddv = 3 * d;
+    a.B = B; a.H = H; a.Lq = L; a.Lk = L; a.scale = 0.125f;
+    a.thr = gct_drop_threshold(0.1f); a.keep_scale = 1.f / 0.9f; a.rng = gct_rng_make(1, 1);
+    a.stamps = st;
+    const size_t lds = (size_t)(320) * 68 * 4 + 80 * 8 + 80 * 80 + MAPS_BYTES;
+    hipFuncSetAttribute((const void*)attn_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int rep = 0; rep < 3; ++rep) {
+      hipMemset(st, 0, 64 * 12 * 8 * 8);
+      hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(B * H), dim3(BWD_THREADS), lds, 0, a);
+      hipDeviceSynchronize();
+    }
+    std::vector<unsigned long long> hs(64 * 12 * 8);
+    hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
+    const char* nm[4] = {"stage+flags", "delta+sync", "maps+sync", "unit"};
+    for (int w = 0; w < 12; w += 5) {
+      double seg[8] = {0};
+      for (int b = 0; b < 64; ++b) for (int i = 0; i < 8; ++i) seg[i] += (double)hs[(b * 12 + w) * 8 + i] / 64;
+      printf(" bwd wave %d:", w);
+      for (int i = 0; i < 4; ++i) printf("  %s %.0f", nm[i], seg[i]);
       printf("\n");
     }
   }
