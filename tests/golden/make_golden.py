@@ -16,6 +16,7 @@ Fixtures:
   g1_known_answers.json   Norm / PE / nopeak_mask known answers
   g2_<type>.pt            tiny config: inputs, eps, outputs, loss, all gradients,
                           sha256 of every initial tensor (seed 1)
+  g2_pvaetf_cond2dec.pt   the same for pvaetf with -use_cond2dec (prop head, MSE term, block mask)
   g3_history.json         tiny-config 5-step Train.trainer1.run_epoch histories
   g5_decode.pt            tiny-config greedy decode token ids (loop restated around
                           the reference's model.decode)
@@ -142,6 +143,36 @@ def g2(mtype):
     return model, batch
 
 
+def g2_cond2dec():
+    """pvaetf with -use_cond2dec (cond tokens prepended to the decoder stream, block mask of
+    Model/modules.py:19-26, prop_fc head + MSE term of Train/trainer1.py:24-26)."""
+    mtype = "pvaetf"
+    vs, vt = synthetic.vocab_sizes(mtype)
+    torch.manual_seed(1)
+    model = Cvaetf(vs, vt, dropout=0.0, nconds=3, use_cond2dec=True, use_cond2lat=False, **TINY)
+    model.train()
+    init_sha = {k: sha(v) for k, v in model.state_dict().items()}
+    ds = synthetic.make_dataset(4, max_len=20, model_type=mtype, seed=7)
+    batch = {k: v for k, v in ds.items()}
+    eps = torch.randn(4, 23, TINY["latent_dim"], generator=torch.Generator().manual_seed(123))
+    real = torch.randn_like
+    torch.randn_like = lambda t, **kw: eps.clone()
+    try:
+        prop, mol, mu, lv, z = ref_fp.forward_propagation[mtype](model, batch, PAD, True)
+    finally:
+        torch.randn_like = real
+    ys = batch["trg"][:, 1:].contiguous().view(-1)
+    ys_cond = batch["dconds"].unsqueeze(2).contiguous().view(-1, 3, 1)
+    loss, rce, rce_prop, kld = ref_tr.loss_function(0.04, prop, mol, ys_cond, ys, mu, lv, True, PAD)
+    loss.backward()
+    grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    torch.save({"init_sha256": init_sha, "param_order": [n for n, _ in model.named_parameters()],
+                "batch": batch, "eps": eps, "beta": 0.04, "prop": prop.detach(), "logits": mol.detach(),
+                "mu": mu.detach(), "log_var": lv.detach(), "loss": float(loss.detach()),
+                "rce": float(rce.detach()), "rce_prop": float(rce_prop.detach()), "kld": float(kld.detach()),
+                "grads": grads}, os.path.join(HERE, "g2_pvaetf_cond2dec.pt"))
+
+
 def g3():
     """5-step run_epoch history on the tiny config, dropout 0, all four types."""
     out = {}
@@ -246,6 +277,7 @@ if __name__ == "__main__":
         g1()
         for t in REF_CLASS:
             g2(t)
+        g2_cond2dec()
         g3()
         g5()
         print("tiny fixtures written")

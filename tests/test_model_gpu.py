@@ -358,3 +358,33 @@ def test_side_stream_wgrad_gives_identical_gradients(golden_dir, monkeypatch):
     assert grads[0].keys() == grads[1].keys()
     for k in grads[0]:
         assert torch.equal(grads[0][k], grads[1][k]), k
+
+
+def test_cond2dec_path_vs_reference(golden_dir):
+    """HIP path with -use_cond2dec against the reference fixture: decoder cond tokens, [B,T+3,T+3]
+    block mask, prop_fc head (N=1 GEMM) and the MSE term."""
+    from gct_plus_amd.Model import forward_propagation, model_dict
+    from gct_plus_amd.Train.trainer1 import loss_function
+    fx = torch.load(os.path.join(golden_dir, "g2_pvaetf_cond2dec.pt"), weights_only=True)
+    torch.manual_seed(1)
+    model = model_dict["pvaetf"](28, 30, dropout=0.0, nconds=3, use_cond2dec=True, use_cond2lat=False,
+                                 **TINY).cuda().train()
+    assert list(model.state_dict().keys()) == list(fx["init_sha256"].keys())
+    set_eps(model, fx["eps"])
+    b = to_dev(fx["batch"])
+    prop, mol, mu, lv, z = forward_propagation["pvaetf"](model, b, PAD, True)
+    assert_close(prop, fx["prop"], 1e-4, 1e-4, "prop")
+    assert_close(mol, fx["logits"], 1e-4, 1e-4, "logits")
+    ys = b["trg"][:, 1:].contiguous().view(-1)
+    ys_cond = b["dconds"].unsqueeze(2).contiguous().view(-1, 3, 1)
+    loss, rce, rce_prop, kld = loss_function(fx["beta"], prop, mol, ys_cond, ys, mu, lv, True, PAD)
+    for got, key in ((loss, "loss"), (rce, "rce"), (rce_prop, "rce_prop"), (kld, "kld")):
+        assert abs(float(got) - fx[key]) <= 2e-5 * abs(fx[key]) + 1e-6, (key, float(got), fx[key])
+    loss.backward()
+    floor = grad_floor(fx["grads"].values())
+    for name, p in model.named_parameters():
+        if name not in fx["grads"]:
+            assert p.grad is None, name
+            continue
+        e = fx["grads"][name]
+        assert_close(p.grad, e, 1e-5 * float(e.abs().max()) + floor, 1e-3, "grad " + name)

@@ -134,3 +134,28 @@ def test_greedy_decode(golden_dir):
 def test_schedules():
     assert abs(O.kl_beta(1) - 0.04) < 1e-12                        # 0.04 at epoch 1
     assert abs(O.warmup_lr(1, 512, 8000) - 512 ** -0.5 * 8000 ** -1.5) < 1e-18
+
+
+def test_cond2dec_path(golden_dir):
+    """-use_cond2dec: cond tokens in the decoder stream, block mask, prop_fc head + MSE term."""
+    fx = torch.load(os.path.join(golden_dir, "g2_pvaetf_cond2dec.pt"), weights_only=True)
+    cfg = O.make_cfg("pvaetf", 28, 30, N=2, d_model=64, dff=128, h=4, latent_dim=16, dropout=0.0,
+                     nconds=3, use_cond2dec=True, use_cond2lat=False)
+    st = O.init_state(cfg, seed=1)
+    assert list(st.keys()) == list(fx["init_sha256"].keys())
+    for k, v in st.items():
+        assert sha(v) == fx["init_sha256"][k], k
+    P = O.make_leaves(st)
+    b = fx["batch"]
+    src_mask, trg_mask, trg_in = O.batch_masks(cfg, b, synthetic.PAD_ID)
+    prop, mol, mu, lv, _ = O.forward(P, cfg, b["src"], trg_in, src_mask, trg_mask, b["econds"], b["dconds"],
+                                     eps=fx["eps"], train=True)
+    assert torch.allclose(prop, fx["prop"], atol=2e-6) and torch.allclose(mol, fx["logits"], atol=2e-6)
+    ys = b["trg"][:, 1:].contiguous().view(-1)
+    ys_cond = b["dconds"].unsqueeze(2).contiguous().view(-1, 3, 1)
+    loss, rce, rce_prop, kld = O.loss_function(fx["beta"], prop, mol, ys_cond, ys, mu, lv, True, synthetic.PAD_ID)
+    for got, key in ((loss, "loss"), (rce, "rce"), (rce_prop, "rce_prop"), (kld, "kld")):
+        assert abs(got.item() - fx[key]) <= 1e-5 * abs(fx[key]), key
+    loss.backward()
+    for name, e in fx["grads"].items():
+        assert torch.allclose(P[name].grad, e, atol=1e-5 * float(e.abs().max()) + 1e-7, rtol=1e-4), name
