@@ -418,8 +418,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
 // =====================================================================================
 struct FastEpi {
   const GemmArgs& g;
+  // number of extra float4 reads per patch row this epilogue needs (resid / accumulate / pre_in)
+  __device__ __forceinline__ bool needs_extra() const {
+    return g.epi == GCT_EPI_DROP_RESID || g.epi == EPI_D0 + GCT_DEPI_ACCUM ||
+           g.epi == EPI_D0 + GCT_DEPI_GELU_BWD;
+  }
+  __device__ __forceinline__ const float* extra_base(const float* cbase) const {
+    return g.epi == GCT_EPI_DROP_RESID ? g.resid
+                                       : (g.epi == EPI_D0 + GCT_DEPI_GELU_BWD ? g.pre_in : cbase);
+  }
+  // issue the extra reads of one 4x4 patch (latency overlaps the other patches' work)
+  __device__ __forceinline__ void prefetch(float4 (&x)[4], int64_t row0, const float* cbase,
+                                           int64_t cloc) const {
+    const float* eb = extra_base(cbase);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      x[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + rr < g.M) x[rr] = *reinterpret_cast<const float4*>(eb + (row0 + rr) * g.ldc + cloc);
+    }
+  }
   __device__ __forceinline__ void apply(float4 (&v)[4], int64_t row0, int64_t col0,
                                         float* cbase, int64_t cloc, float4 bias) const {
+    float4 x[4];
+    if (needs_extra()) prefetch(x, row0, cbase, cloc);
+    apply(v, x, row0, col0, cbase, cloc, bias);
+  }
+  __device__ __forceinline__ void apply(float4 (&v)[4], const float4 (&ex)[4], int64_t row0,
+                                        int64_t col0, float* cbase, int64_t cloc, float4 bias) const {
     // v[rr] = 4 consecutive columns (col0..col0+3) of row row0+rr; row0 % 4 == 0
     const int epi = g.epi;
     uint4 bits[4];
@@ -452,16 +477,16 @@ struct FastEpi {
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) x[cc] = keep[cc] ? gct_gelu(x[cc]) * g.keep_scale : 0.f;
       } else if (epi == GCT_EPI_DROP_RESID) {
-        const float4 r = *reinterpret_cast<const float4*>(g.resid + off);
+        const float4 r = ex[rr];
         const float rs[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc)
           x[cc] = (keep[cc] ? (x[cc] + bs[cc]) * g.keep_scale : 0.f) + rs[cc];
       } else if (epi == EPI_D0 + GCT_DEPI_ACCUM) {
-        const float4 r = *reinterpret_cast<const float4*>(cbase + off);
+        const float4 r = ex[rr];
         x[0] += r.x; x[1] += r.y; x[2] += r.z; x[3] += r.w;
       } else if (epi == EPI_D0 + GCT_DEPI_GELU_BWD) {
-        const float4 u = *reinterpret_cast<const float4*>(g.pre_in + off);
+        const float4 u = ex[rr];
         const float us[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc)
@@ -700,29 +725,45 @@ gemm_f32_fast_kernel(const GemmArgs g) {
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes are visible to it
   __builtin_amdgcn_wave_barrier();
   const FastEpi ep{g};
+  {
+    // the lane's column chunk is the same for its 4 patches: destination, bias and the
+    // segment select are resolved once; the residual / accumulate / pre-activation rows of
+    // all 4 patches are requested up front so their latency overlaps
+    const int c4 = lane & 15;
+    const int64_t col0 = n0 + wn + c4 * 4;
+    if (col0 < g.N) {
+      float* cbase;
+      int64_t cloc;
+      float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g.epi == EPI_SLAB) {
+        cbase = g.c0 + (int64_t)z * g.slab_stride;
+        cloc = col0;
+      } else {
+        const bool g1 = col0 >= g.c_nper, g2 = col0 >= 2 * g.c_nper;
+        cloc = col0 - (g2 ? 2 * g.c_nper : (g1 ? g.c_nper : 0));
+        cbase = g.c0 + (g2 ? g.c_d2 : (g1 ? g.c_d1 : 0));
+        if (g.epi < EPI_D0 && g.bias0)
+          bias = *reinterpret_cast<const float4*>(g.bias0 + (g2 ? g.bias_d2 : (g1 ? g.bias_d1 : 0)) + cloc);
+      }
+      float4 ex[4][4];
+      const bool extra = ep.needs_extra();
+      if (extra) {
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int rg = it * 4 + (lane >> 4), c4 = lane & 15;
-    const int64_t row0 = m0 + wm + rg * 4, col0 = n0 + wn + c4 * 4;
-    if (row0 >= g.M || col0 >= g.N) continue;
-    float4 v[4];
+        for (int it = 0; it < 4; ++it)
+          ep.prefetch(ex[it], m0 + wm + (it * 4 + (lane >> 4)) * 4, cbase, cloc);
+      }
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
-      v[rr] = *reinterpret_cast<const float4*>(stg + (rg * 4 + rr) * 64 + c4 * 4);
-    float* cbase;
-    int64_t cloc;
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.epi == EPI_SLAB) {
-      cbase = g.c0 + (int64_t)z * g.slab_stride;
-      cloc = col0;
-    } else {
-      const bool g1 = col0 >= g.c_nper, g2 = col0 >= 2 * g.c_nper;
-      cloc = col0 - (g2 ? 2 * g.c_nper : (g1 ? g.c_nper : 0));
-      cbase = g.c0 + (g2 ? g.c_d2 : (g1 ? g.c_d1 : 0));
-      if (g.epi < EPI_D0 && g.bias0)
-        bias = *reinterpret_cast<const float4*>(g.bias0 + (g2 ? g.bias_d2 : (g1 ? g.bias_d1 : 0)) + cloc);
+      for (int it = 0; it < 4; ++it) {
+        const int rg = it * 4 + (lane >> 4);
+        const int64_t row0 = m0 + wm + rg * 4;
+        if (row0 >= g.M) continue;
+        float4 v[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          v[rr] = *reinterpret_cast<const float4*>(stg + (rg * 4 + rr) * 64 + c4 * 4);
+        ep.apply(v, ex[it], row0, col0, cbase, cloc, bias);
+      }
     }
-    ep.apply(v, row0, col0, cbase, cloc, bias);
   }
 #ifdef GCT_STAMPS
   STAMP(6);  // epilogue
