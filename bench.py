@@ -163,7 +163,7 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "r01_gemm_fwd_traffic.json")
             if os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            roof = {"kernel": "gemm_f32_kernel<A_KC,B_KC> (nn.Linear forward, all shapes)",
+            roof = {"kernel": "gemm_f32_fast_kernel<true,true> (nn.Linear forward, every shape of the step)",
                     "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
                     "traffic": traffic, "avg_launch_us": kern[dom]["avg_us"],

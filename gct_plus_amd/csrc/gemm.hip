@@ -63,6 +63,7 @@ struct GemmArgs {
   uint32_t thr;
   GctRng rng;
   float* bias_slab;  // wgrad fast path: per-split column sums of dY, [nsplit][M] (nullptr: off)
+  int stagger;       // s_sleep(127) repeats for the second resident workgroup of each CU
 #ifdef GCT_STAMPS
   unsigned long long* stamps;  // diagnostic build only (tools/gemm_stamps.hip)
 #endif
@@ -503,6 +504,13 @@ gemm_f32_fast_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];  // A0 B0 A1 B1 : 64 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  // Two workgroups share a CU and, started together, stay in lockstep: their prologues and
+  // epilogues coincide and the MFMA pipe idles.  Delaying the second resident workgroup of the
+  // first dispatch round by about half a tile de-phases them for the rest of the launch (tiles
+  // have equal duration, so the offset persists).  Placement is a speed guess only.
+  if (g.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+    for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   const unsigned tiles_n = (unsigned)((g.N + BN - 1) / BN);
   const unsigned tiles_m = (unsigned)((g.M + BM - 1) / BM);
@@ -942,6 +950,7 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
   }
   dim3 grid((unsigned)tiles), block(256);
   const bool fast = fast_ok<A_KC, B_KC>(g, vec);
+  static const int stagger_env = getenv("GCT_GEMM_STAGGER") ? atoi(getenv("GCT_GEMM_STAGGER")) : -1;
   // skinny M (decode steps): 64x64 tiles when the 128x128 grid would leave most CUs idle
   if (fast && A_KC && B_KC && g.nsplit == 1 && tiles < 192 && g.epi < EPI_D0 &&
       (g.b_nper >= g.N || g.b_nper % 64 == 0)) {
@@ -972,8 +981,17 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
     GCT_LAUNCH_CHECK("splitk_epilogue");
     return GCT_OK;
   }
-  if (fast)
-    hipLaunchKernelGGL((gemm_f32_fast_kernel<A_KC, B_KC>), grid, block, 0, st, g);
+  if (fast) {
+    GemmArgs gs = g;
+    // half of one tile's main loop: nkt K-tiles x ~4.5k cycles / 2, in units of s_sleep(127) ~ 8.1k cycles
+    const int64_t nkt = (g.ksplit < g.K ? g.ksplit : g.K) / BK;
+    // measured (tools/kernel_bench.py, GCT_GEMM_STAGGER=0/2/4/8): within +-2 % on every shape, so the
+    // stagger is OFF unless requested -- kept as an experiment knob
+    (void)nkt;
+    gs.stagger = stagger_env > 0 ? stagger_env : 0;
+    if (tiles <= 512) gs.stagger = 0;      // a single round: nothing to de-phase
+    hipLaunchKernelGGL((gemm_f32_fast_kernel<A_KC, B_KC>), grid, block, 0, st, gs);
+  }
   else if (vec)
     hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true>), grid, block, 0, st, g);
   else
