@@ -1,0 +1,100 @@
+"""Edge cases of the hot path on the GPU, each against the CPU oracle: odd batch sizes and
+lengths (row counts not multiples of 4 / 16 / 128), minimum and maximum sequence lengths,
+fully padded tails, variational=False, and loud failure past the supported length."""
+import pytest
+import torch
+
+from gct_plus_amd import synthetic
+from oracle import gct_oracle as O
+
+pytestmark = pytest.mark.gpu
+PAD = synthetic.PAD_ID
+
+
+def make(mtype, kw, seed=2, **over):
+    from gct_plus_amd.Model import model_dict
+    vs, vt = synthetic.vocab_sizes(mtype)
+    nc = synthetic.n_conds(mtype)
+    torch.manual_seed(seed)
+    m = model_dict[mtype](vs, vt, dropout=0.0, nconds=nc, use_cond2lat=True, **kw, **over).cuda().train()
+    cfg = O.make_cfg(mtype, vs, vt, dropout=0.0, nconds=nc, use_cond2lat=True,
+                     variational=over.get("variational", True), **kw)
+    P = O.make_leaves({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    return m, cfg, P
+
+
+def compare(mtype, m, cfg, P, ds, beta=0.1, seed=0):
+    from gct_plus_amd.Model import forward_propagation
+    from gct_plus_amd.Train.trainer1 import loss_function
+    nc = cfg["nconds"]
+    B, S = ds["src"].shape
+    eps = torch.randn(B, S + nc, cfg["latent_dim"], generator=torch.Generator().manual_seed(seed))
+    (m.sampler if hasattr(m, "sampler") else m.encoder).eps_override = eps
+    b = {k: v.cuda() for k, v in ds.items()}
+    prop, mol, mu, lv, z = forward_propagation[mtype](m, b, PAD, False)
+    sm, tm, trg_in = O.batch_masks(cfg, ds, PAD)
+    _, omol, omu, olv, oz = O.forward(P, cfg, ds["src"], trg_in, sm, tm, ds.get("econds"), ds.get("dconds"),
+                                      eps=eps, train=True)
+    for got, ref, name in ((mol, omol, "logits"), (mu, omu, "mu"), (lv, olv, "log_var"), (z, oz, "z")):
+        assert torch.allclose(got.cpu(), ref, atol=1e-4, rtol=1e-4), (name, float((got.cpu() - ref).abs().max()))
+    assert torch.equal(mol.argmax(-1).cpu(), omol.argmax(-1))
+    ys = b["trg"][:, 1:].contiguous().view(-1)
+    yc = b["dconds"].unsqueeze(2).contiguous().view(-1, nc, 1) if nc else None
+    loss = loss_function(beta, prop, mol, yc, ys, mu, lv, False, PAD)[0]
+    oloss = O.loss_function(beta, None, omol, None if not nc else ds["dconds"].unsqueeze(2), ds["trg"][:, 1:].reshape(-1),
+                            omu, olv, False, PAD)[0]
+    assert abs(loss.item() - oloss.item()) <= 3e-5 * abs(oloss.item())
+    loss.backward()
+    oloss.backward()
+    gmax = max(float(v.grad.abs().max()) for v in P.values() if v.grad is not None)
+    for n, p in m.named_parameters():
+        if P[n].grad is None:
+            assert p.grad is None
+            continue
+        e = P[n].grad
+        tol = 1e-5 * float(e.abs().max()) + 2e-6 * gmax
+        assert torch.allclose(p.grad.cpu(), e, atol=tol, rtol=1e-3), (n, float((p.grad.cpu() - e).abs().max()))
+
+
+TINY = dict(N=2, d_model=64, dff=128, h=4, latent_dim=16)
+
+
+@pytest.mark.parametrize("mtype,B,S", [("vaetf", 1, 1), ("vaetf", 3, 5), ("pscavaetf", 5, 33), ("pvaetf", 7, 15),
+                                       ("scavaetf", 2, 17), ("vaetf", 130, 9)])
+def test_odd_shapes(mtype, B, S):
+    m, cfg, P = make(mtype, TINY)
+    ds = synthetic.make_dataset(B, S, mtype, seed=B * 100 + S)
+    if S >= 8:                                   # ragged: shorten some rows by hand
+        for i in range(1, B):
+            ln = 2 + (i * 5) % (S - 2)
+            ds["src"][i, ln:] = PAD
+            ds["trg"][i, ln + 1] = synthetic.EOS_ID
+            ds["trg"][i, ln + 2:] = PAD
+    compare(mtype, m, cfg, P, ds)
+
+
+def test_maximum_length_and_beyond():
+    """L_k = 128 is the kernels' limit (the reference's PE table allows 200, its data never exceeds
+    ~86): n_c + S = 3 + 122 = 125 encoder rows, cross keys 128, decoder 123."""
+    m, cfg, P = make("pvaetf", TINY)
+    ds = synthetic.make_dataset(2, 122, "pvaetf", seed=1, fixed_len=True)
+    compare("pvaetf", m, cfg, P, ds)
+    from gct_plus_amd import _lib
+    from gct_plus_amd.Model import forward_propagation
+    big = {k: v.cuda() for k, v in synthetic.make_dataset(2, 130, "pvaetf", seed=1).items()}
+    with pytest.raises(_lib.GctError, match="sequence length"):
+        forward_propagation["pvaetf"](m, big, PAD, False)
+
+
+def test_non_variational():
+    m, cfg, P = make("vaetf", TINY, variational=False)
+    ds = synthetic.make_dataset(4, 12, "vaetf", seed=3)
+    compare("vaetf", m, cfg, P, ds)
+
+
+def test_head_dims_32_and_full_size_heads():
+    """d_k = 32 (d_model 128 / 4 heads) exercises the NDT=2 attention instantiation."""
+    kw = dict(N=1, d_model=128, dff=256, h=4, latent_dim=32)
+    m, cfg, P = make("pscavaetf", kw)
+    ds = synthetic.make_dataset(6, 21, "pscavaetf", seed=9)
+    compare("pscavaetf", m, cfg, P, ds)
