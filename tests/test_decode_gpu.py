@@ -79,3 +79,46 @@ def test_multinomial_matches_probabilities():
     assert float((freq - p).abs().max()) < 0.03
     assert torch.equal(valid[:, 1].cpu().bool(), ys[:, 1].cpu() != synthetic.PAD_ID)
     assert torch.equal(done.cpu().bool(), ys[:, 1].cpu() == synthetic.EOS_ID)
+
+
+def test_sampling_front_end_all_model_types():
+    """sample_smiles of every model type runs on the KV-cached decoder and returns the strings of
+    the token ids the un-cached reference-style loop produces for the same z / prefix."""
+    from gct_plus_amd import data
+    from gct_plus_amd.Inference.sampling_tool import get_sampler, sample_token_lengths
+    from gct_plus_amd.decode import reference_style_decode
+    from tests.test_data_pipeline import SMILES
+    import numpy as np
+    lens = sample_token_lengths([20, 25, 25, 30, 31, 40, 22, 28], 500, np.random.default_rng(0))
+    assert 15 <= lens.min() and lens.max() <= 45 and abs(lens.mean() - 27.6) < 2.5
+    for mtype in ("vaetf", "pvaetf", "scavaetf", "pscavaetf"):
+        sep = mtype in ("scavaetf", "pscavaetf")
+        strs = [("c1ccccc1<sep>" + s) if sep else s for s in SMILES]
+        SRC, TRG = data.Vocab.build(strs, False, sep), data.Vocab.build(strs, True, sep)
+        from gct_plus_amd.Model import model_dict
+        nc = synthetic.n_conds(mtype)
+        torch.manual_seed(4)
+        model = model_dict[mtype](len(SRC), len(TRG), dropout=0.1, nconds=nc, use_cond2lat=True, **TINY).cuda().eval()
+        sp = get_sampler(mtype, model, SRC, TRG, latent_dim=16, max_strlen=24, cond_dim=nc,
+                         toklen_data=[12, 14, 15, 18, 20, 16])
+        n = 6
+        args = {"vaetf": (n,), "pvaetf": (np.zeros((n, 3)),), "scavaetf": (n, "c1ccccc1"),
+                "pscavaetf": (np.ones((n, 3)) * 0.3, "c1ccccc1")}[mtype]
+        kw = {} if nc == 0 else {"transform": False}
+        smiles, toklen, toklen_gen = sp.sample_smiles(*args, **kw)
+        assert len(smiles) == n and all(isinstance(s, str) for s in smiles) and len(toklen) == n
+        ys = sp.kv.ys[:, :sp.kv.ys.shape[1]]
+        # same z again through the un-cached loop
+        z = None
+        if mtype in ("vaetf", "pvaetf"):
+            z = torch.randn(n, 20 + nc, 16)
+            a2 = (n,) if mtype == "vaetf" else args
+            s1, _, _ = sp.sample_smiles(*a2, zs=z, **kw)
+            src_mask = torch.ones(n, 1, z.size(1), dtype=torch.bool, device="cuda")
+            dc = None if nc == 0 else torch.zeros(n, 3, device="cuda")
+            ref = reference_style_decode(model, z.cuda(), src_mask, dc, sp.init_y(n).cuda(), sp.pad_id, sp.eos_id, 24)
+            assert s1 == [sp.id_to_smi(r) for r in ref.cpu().numpy()]
+        # encode path (Sampling.encode_smiles -> model.encode)
+        if mtype == "vaetf":
+            zz, mu, lv = sp.encode_smiles(SMILES[:3])
+            assert mu.shape[0] == 3 and mu.shape[2] == 16
