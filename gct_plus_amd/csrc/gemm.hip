@@ -64,6 +64,8 @@ struct GemmArgs {
   GctRng rng;
   float* bias_slab;  // wgrad fast path: per-split column sums of dY, [nsplit][M] (nullptr: off)
   int stagger;       // s_sleep(127) repeats for the second resident workgroup of each CU
+  const uint16_t* bp0;  // bf16x6 kernels: pre-split planes of the B operand (same element offsets as b)
+  int64_t bp_stride;    // elements between the hi / mid / lo planes
 #ifdef GCT_STAMPS
   unsigned long long* stamps;  // diagnostic build only (tools/gemm_stamps.hip)
 #endif
@@ -498,6 +500,65 @@ struct FastEpi {
   }
 };
 
+
+// Per-wave epilogue shared by the 128x128 fp32-MFMA kernel and the bf16x6 kernels (both leave a
+// 64x64 block per wave in the 32x32 MFMA accumulator layout): transpose through LDS (stg: 64x64
+// floats private to the wave), then every lane finishes 4 patches of 4 rows x 4 columns.
+__device__ __forceinline__ void wave_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][2], float* stg,
+                                              int lane, int64_t mw, int64_t nw, unsigned z) {
+  {
+    const int h = lane >> 5, c32 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stg[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + c32] = acc[i][j][r];
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes are visible to it
+  __builtin_amdgcn_wave_barrier();
+  const FastEpi ep{g};
+  // the lane's column chunk is the same for its 4 patches: destination, bias and the
+  // segment select are resolved once; the residual / accumulate / pre-activation rows of
+  // all 4 patches are requested up front so their latency overlaps
+  const int c4 = lane & 15;
+  const int64_t col0 = nw + c4 * 4;
+  if (col0 < g.N) {
+    float* cbase;
+    int64_t cloc;
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.epi == EPI_SLAB) {
+      cbase = g.c0 + (int64_t)z * g.slab_stride;
+      cloc = col0;
+    } else {
+      const bool g1 = col0 >= g.c_nper, g2 = col0 >= 2 * g.c_nper;
+      cloc = col0 - (g2 ? 2 * g.c_nper : (g1 ? g.c_nper : 0));
+      cbase = g.c0 + (g2 ? g.c_d2 : (g1 ? g.c_d1 : 0));
+      if (g.epi < EPI_D0 && g.bias0)
+        bias = *reinterpret_cast<const float4*>(g.bias0 + (g2 ? g.bias_d2 : (g1 ? g.bias_d1 : 0)) + cloc);
+    }
+    float4 ex[4][4];
+    const bool extra = ep.needs_extra();
+    if (extra) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        ep.prefetch(ex[it], mw + (it * 4 + (lane >> 4)) * 4, cbase, cloc);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rg = it * 4 + (lane >> 4);
+      const int64_t row0 = mw + rg * 4;
+      if (row0 >= g.M) continue;
+      float4 v[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        v[rr] = *reinterpret_cast<const float4*>(stg + (rg * 4 + rr) * 64 + c4 * 4);
+      ep.apply(v, ex[it], row0, col0, cbase, cloc, bias);
+    }
+  }
+}
+
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 gemm_f32_fast_kernel(const GemmArgs g) {
@@ -719,60 +780,7 @@ gemm_f32_fast_kernel(const GemmArgs g) {
 #undef GCT_PIN
 
   // ---- epilogue: per-wave 64x64 transpose through LDS (the tile buffers are free now)
-  float* stg = lds + wave * 4096;  // 64 rows x 64 cols
-  {
-    const int h = lane >> 5, c32 = lane & 31;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          stg[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + c32] = acc[i][j][r];
-  }
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes are visible to it
-  __builtin_amdgcn_wave_barrier();
-  const FastEpi ep{g};
-  {
-    // the lane's column chunk is the same for its 4 patches: destination, bias and the
-    // segment select are resolved once; the residual / accumulate / pre-activation rows of
-    // all 4 patches are requested up front so their latency overlaps
-    const int c4 = lane & 15;
-    const int64_t col0 = n0 + wn + c4 * 4;
-    if (col0 < g.N) {
-      float* cbase;
-      int64_t cloc;
-      float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g.epi == EPI_SLAB) {
-        cbase = g.c0 + (int64_t)z * g.slab_stride;
-        cloc = col0;
-      } else {
-        const bool g1 = col0 >= g.c_nper, g2 = col0 >= 2 * g.c_nper;
-        cloc = col0 - (g2 ? 2 * g.c_nper : (g1 ? g.c_nper : 0));
-        cbase = g.c0 + (g2 ? g.c_d2 : (g1 ? g.c_d1 : 0));
-        if (g.epi < EPI_D0 && g.bias0)
-          bias = *reinterpret_cast<const float4*>(g.bias0 + (g2 ? g.bias_d2 : (g1 ? g.bias_d1 : 0)) + cloc);
-      }
-      float4 ex[4][4];
-      const bool extra = ep.needs_extra();
-      if (extra) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-          ep.prefetch(ex[it], m0 + wm + (it * 4 + (lane >> 4)) * 4, cbase, cloc);
-      }
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int rg = it * 4 + (lane >> 4);
-        const int64_t row0 = m0 + wm + rg * 4;
-        if (row0 >= g.M) continue;
-        float4 v[4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-          v[rr] = *reinterpret_cast<const float4*>(stg + (rg * 4 + rr) * 64 + c4 * 4);
-        ep.apply(v, ex[it], row0, col0, cbase, cloc, bias);
-      }
-    }
-  }
+  wave_epilogue(g, acc, lds + wave * 4096, lane, m0 + wm, n0 + wn, z);
 #ifdef GCT_STAMPS
   STAMP(6);  // epilogue
   if (g.stamps && (threadIdx.x & 63) == 0 && blockIdx.x < 64) {
@@ -781,6 +789,8 @@ gemm_f32_fast_kernel(const GemmArgs g) {
 #endif
 }
 
+
+#include "gemm_x6.inc"
 
 // =====================================================================================
 // SKINNY-M forward kernel (KV-cached decode: M = batch rows per step = 512): 64x64 tiles, 4 waves
@@ -925,6 +935,19 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs g, 
   ep.apply(v, row0, col0, cbase, cloc, bias);
 }
 
+// GEMM arithmetic: GCT_GEMM_F32 = v_mfma_f32_32x32x2_f32 everywhere; GCT_GEMM_BF16X6 = exact 3-way bf16
+// split with six partial products (gemm_x6.inc) wherever a launch qualifies.  Process-wide; the
+// default comes from GCT_GEMM_MODE=f32|x6 (x6 when unset).
+int g_gemm_mode = -1;
+int64_t g_gemm_launches[2] = {0, 0};   // [GCT_GEMM_F32 kernels, bf16x6 kernels] (tests / diagnostics)
+inline int gemm_mode() {
+  if (g_gemm_mode < 0) {
+    const char* e = getenv("GCT_GEMM_MODE");
+    g_gemm_mode = (e && (e[0] == 'f' || e[0] == '0')) ? GCT_GEMM_F32 : GCT_GEMM_BF16X6;
+  }
+  return g_gemm_mode;
+}
+
 // single source of truth for "this launch takes gemm_f32_fast_kernel"
 template <bool A_KC, bool B_KC>
 bool fast_ok(const GemmArgs& g, bool vec) {
@@ -981,6 +1004,14 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
     GCT_LAUNCH_CHECK("splitk_epilogue");
     return GCT_OK;
   }
+  if (gemm_mode() == GCT_GEMM_BF16X6) {
+    constexpr int MODE = A_KC ? (B_KC ? X6_FWD : X6_DGRAD) : X6_WGRAD;
+    if ((A_KC || !B_KC) && x6_ok<MODE>(g, vec)) {
+      ++g_gemm_launches[1];
+      return launch_x6<MODE>(g, st);
+    }
+  }
+  ++g_gemm_launches[0];
   if (fast) {
     GemmArgs gs = g;
     // half of one tile's main loop: nkt K-tiles x ~4.5k cycles / 2, in units of s_sleep(127) ~ 8.1k cycles
@@ -1019,10 +1050,12 @@ int gct_colsum(const float* y0, const float* y1, const float* y2, int64_t ld, in
                int nper, float* d0, float* d1, float* d2, float* ws, hipStream_t st);
 int64_t gct_colsum_ws_floats(int64_t M, int64_t N);
 
-static int wgrad_splits(int64_t M, int64_t Ntot, int64_t K) {
-  const int64_t tiles = ((Ntot + BM - 1) / BM) * ((K + BN - 1) / BN);
+static int wgrad_splits(int64_t M, int64_t Ntot, int64_t K, bool x6 = false) {
+  const int64_t tiles = x6 ? ((Ntot + XBM - 1) / XBM) * ((K + XBN - 1) / XBN)
+                           : ((Ntot + BM - 1) / BM) * ((K + BN - 1) / BN);
   // exactly one resident round: 256 CUs x 2 blocks (64 KB LDS each) = 512 blocks, never 513
-  int64_t want = 512 / tiles;
+  // (bf16x6: one 144 KB workgroup per CU = 256 blocks)
+  int64_t want = (x6 ? 256 : 512) / tiles;
   const int64_t maxs = (M + 4 * BK - 1) / (4 * BK);
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
@@ -1031,7 +1064,8 @@ static int wgrad_splits(int64_t M, int64_t Ntot, int64_t K) {
 }
 
 extern "C" int64_t gct_wgrad_ws_bytes(int64_t M, int64_t Ntot, int64_t K) {
-  const int s = wgrad_splits(M, Ntot, K);
+  const int s1 = wgrad_splits(M, Ntot, K), s2 = wgrad_splits(M, Ntot, K, true);
+  const int s = s1 > s2 ? s1 : s2;
   const int64_t slab = (int64_t)s * Ntot * K;
   const int64_t cs = gct_colsum_ws_floats(M, Ntot);
   const int64_t need = slab + 4 + (int64_t)s * Ntot;   // weight slabs + fused bias slabs
@@ -1043,7 +1077,7 @@ static int linear_fwd_impl(const float* x, int64_t ldx, int64_t M, int K, const 
                            const float* b1, const float* b2, int nseg, int nper, float* y0,
                            float* y1, float* y2, int64_t ldy, int epi, const float* resid,
                            float* pre, float p, uint64_t seed, uint32_t site, float* ws,
-                           void* stream) {
+                           void* stream, const uint16_t* wp0 = nullptr, int64_t pstride = 0) {
   GCT_CHECK_ARG(x && w0 && y0 && M >= 0 && K > 0 && nseg >= 1 && nseg <= 3 && nper > 0,
                 "linear_fwd: bad args");
   GCT_CHECK_ARG(nseg < 2 || (w1 && y1), "linear_fwd: missing segment 1");
@@ -1063,6 +1097,7 @@ static int linear_fwd_impl(const float* x, int64_t ldx, int64_t M, int K, const 
   g.bias0 = b0; g.bias_d1 = (b0 && b1) ? b1 - b0 : 0; g.bias_d2 = (b0 && b2) ? b2 - b0 : 0;
   g.resid = resid; g.pre = pre;
   g.thr = gct_drop_threshold(p); g.keep_scale = 1.0f / (1.0f - p); g.rng = gct_rng_make(seed, site);
+  g.bp0 = wp0; g.bp_stride = pstride;
   const bool vec = al16(x) && al16(w0) && al16(w1) && al16(w2) && (ldx % 4 == 0) &&
                    (ldw % 4 == 0) && (K % 4 == 0);
   return launch<true, true>(g, vec, (hipStream_t)stream, ws);
@@ -1087,17 +1122,52 @@ extern "C" int gct_linear_fwd_ws(const float* x, int64_t ldx, int64_t M, int K, 
                          resid, pre, p, seed, site, ws, stream);
 }
 
+extern "C" int gct_linear_fwd_p(const float* x, int64_t ldx, int64_t M, int K, const float* w0,
+                                const float* w1, const float* w2, int64_t ldw, const uint16_t* wp0,
+                                int64_t plane_stride, const float* b0, const float* b1,
+                                const float* b2, int nseg, int nper, float* y0, float* y1, float* y2,
+                                int64_t ldy, int epi, const float* resid, float* pre, float p,
+                                uint64_t seed, uint32_t site, float* ws, void* stream) {
+  return linear_fwd_impl(x, ldx, M, K, w0, w1, w2, ldw, b0, b1, b2, nseg, nper, y0, y1, y2, ldy, epi,
+                         resid, pre, p, seed, site, ws, stream, wp0, plane_stride);
+}
+
+extern "C" int gct_gemm_set_mode(int mode) {
+  GCT_CHECK_ARG(mode == GCT_GEMM_F32 || mode == GCT_GEMM_BF16X6, "gemm_set_mode: unknown mode %d", mode);
+  g_gemm_mode = mode;
+  return GCT_OK;
+}
+extern "C" int gct_gemm_get_mode(void) { return gemm_mode(); }
+extern "C" int gct_gemm_launch_counts(int64_t* out2) {
+  GCT_CHECK_ARG(out2, "gemm_launch_counts: null");
+  out2[0] = g_gemm_launches[0]; out2[1] = g_gemm_launches[1];
+  return GCT_OK;
+}
+
+extern "C" int gct_split_planes(const float* src, int64_t numel, uint16_t* planes, int64_t plane_stride,
+                                void* stream) {
+  GCT_CHECK_ARG(src && planes && numel >= 0 && numel % 4 == 0 && plane_stride >= numel && plane_stride % 4 == 0 &&
+                    gct_aligned16(src) && ((((uintptr_t)planes) & 7u) == 0),
+                "split_planes: bad args (numel and plane_stride must be multiples of 4, src 16-B aligned)");
+  if (numel == 0) return GCT_OK;
+  const int64_t n4 = numel / 4;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     src, planes, n4, plane_stride);
+  GCT_LAUNCH_CHECK("split_planes");
+  return GCT_OK;
+}
+
 extern "C" int64_t gct_linear_fwd_ws_bytes(int64_t M, int K, int Ntot) {
   // worst case: K/128 slabs of [M][Ntot]; only used for skinny M, so this stays small
   const int64_t ns = K / (4 * BK) > 0 ? K / (4 * BK) : 1;
   return ns * M * Ntot * (int64_t)sizeof(float) + 256;
 }
 
-extern "C" int gct_linear_dgrad(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
-                                int64_t M, int nseg, int nper, const float* w0, const float* w1,
-                                const float* w2, int64_t ldw, int K, float* dx, int64_t lddx,
-                                int depi, const float* pre, float p, uint64_t seed, uint32_t site,
-                                void* stream) {
+static int linear_dgrad_impl(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
+                             int64_t M, int nseg, int nper, const float* w0, const float* w1,
+                             const float* w2, int64_t ldw, int K, float* dx, int64_t lddx,
+                             int depi, const float* pre, float p, uint64_t seed, uint32_t site,
+                             void* stream, const uint16_t* wp0, int64_t pstride) {
   GCT_CHECK_ARG(dy0 && w0 && dx && M >= 0 && K > 0 && nseg >= 1 && nseg <= 3 && nper > 0,
                 "linear_dgrad: bad args");
   GCT_CHECK_ARG(nseg < 2 || (w1 && dy1), "linear_dgrad: missing segment 1");
@@ -1112,9 +1182,29 @@ extern "C" int gct_linear_dgrad(const float* dy0, const float* dy1, const float*
   g.ksplit = g.K; g.nsplit = 1; g.epi = EPI_D0 + depi;
   g.pre_in = pre;
   g.thr = gct_drop_threshold(p); g.keep_scale = 1.0f / (1.0f - p); g.rng = gct_rng_make(seed, site);
+  g.bp0 = wp0; g.bp_stride = pstride;
   const bool vec = al16(dy0) && al16(dy1) && al16(dy2) && al16(w0) && al16(w1) && al16(w2) &&
                    (lddy % 4 == 0) && (ldw % 4 == 0) && (nper % 4 == 0) && (K % 4 == 0);
   return launch<true, false>(g, vec, (hipStream_t)stream);
+}
+
+extern "C" int gct_linear_dgrad(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
+                                int64_t M, int nseg, int nper, const float* w0, const float* w1,
+                                const float* w2, int64_t ldw, int K, float* dx, int64_t lddx,
+                                int depi, const float* pre, float p, uint64_t seed, uint32_t site,
+                                void* stream) {
+  return linear_dgrad_impl(dy0, dy1, dy2, lddy, M, nseg, nper, w0, w1, w2, ldw, K, dx, lddx, depi, pre,
+                           p, seed, site, stream, nullptr, 0);
+}
+
+extern "C" int gct_linear_dgrad_p(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
+                                  int64_t M, int nseg, int nper, const float* w0, const float* w1,
+                                  const float* w2, int64_t ldw, const uint16_t* wp0,
+                                  int64_t plane_stride, int K, float* dx, int64_t lddx, int depi,
+                                  const float* pre, float p, uint64_t seed, uint32_t site,
+                                  void* stream) {
+  return linear_dgrad_impl(dy0, dy1, dy2, lddy, M, nseg, nper, w0, w1, w2, ldw, K, dx, lddx, depi, pre,
+                           p, seed, site, stream, wp0, plane_stride);
 }
 
 extern "C" int gct_linear_wgrad(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
@@ -1128,26 +1218,28 @@ extern "C" int gct_linear_wgrad(const float* dy0, const float* dy1, const float*
   GCT_CHECK_ARG(lddw == K, "linear_wgrad: dW must be dense [nper][K]");
   hipStream_t st = (hipStream_t)stream;
   const int64_t Ntot = (int64_t)nseg * nper;
-  const int splits = wgrad_splits(M, Ntot, K);
+  const bool vec = al16(dy0) && al16(dy1) && al16(dy2) && al16(x) && (lddy % 4 == 0) &&
+                   (ldx % 4 == 0) && (nper % 4 == 0) && (K % 4 == 0);
   GemmArgs g = {};
   g.M = Ntot; g.N = K; g.K = M;  // dW[n][k] = sum_m dY[m][n] X[m][k]
   g.a = mkseg(dy0, dy1, dy2); g.lda = lddy; g.a_nper = nper;
   g.b = mkseg(x, nullptr, nullptr); g.ldb = ldx; g.b_nper = INT64_MAX / 4;
   g.c0 = ws; g.ldc = K; g.c_nper = INT64_MAX / 4;
   g.slab_stride = Ntot * K;
+  g.ksplit = BK; g.nsplit = 1; g.epi = EPI_SLAB;
+  const bool use_x6 = gemm_mode() == GCT_GEMM_BF16X6 && x6_ok<X6_WGRAD>(g, vec);
+  const int splits = wgrad_splits(M, Ntot, K, use_x6);
   int64_t ks = (M + splits - 1) / splits;
   ks = (ks + BK - 1) / BK * BK;
   g.ksplit = ks > 0 ? ks : BK;
   g.nsplit = (int)((M + g.ksplit - 1) / g.ksplit);
   if (g.nsplit < 1) g.nsplit = 1;
   g.epi = EPI_SLAB;
-  const bool vec = al16(dy0) && al16(dy1) && al16(dy2) && al16(x) && (lddy % 4 == 0) &&
-                   (ldx % 4 == 0) && (nper % 4 == 0) && (K % 4 == 0);
   // bias gradients: fused into the GEMM on the fast path (column sums of the A tiles), else a
   // separate column-sum pass that borrows ws before the slabs are written (stream-ordered)
   float* bslab = nullptr;
   if (db0) {
-    if (fast_ok<false, false>(g, vec)) {
+    if (use_x6 || fast_ok<false, false>(g, vec)) {
       int64_t off = (int64_t)g.nsplit * g.slab_stride;
       off = (off + 3) / 4 * 4;
       bslab = ws + off;                     // [nsplit][Ntot] right behind the weight slabs

@@ -43,6 +43,8 @@ class KVDecoder:
         dec, d = self.dec, self.d
         dev = z.device
         n, Le, lat = z.shape
+        if hasattr(self.model, "refresh_weight_planes"):
+            self.model.refresh_weight_planes()         # the prefill GEMMs may take the bf16x6 path
         nc = dec.nconds
         c2l = dec.use_cond2lat and nc > 0
         z2 = z.reshape(n * Le, lat).float().contiguous()

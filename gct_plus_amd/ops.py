@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from typing import List, Optional, Sequence
 
 import torch
@@ -177,6 +178,73 @@ def _seg3(ts: Sequence[Optional[torch.Tensor]]):
     return [_p(t) for t in ts]
 
 
+# ---- bf16x6 GEMM mode: pre-split weight planes --------------------------------------------------
+GEMM_F32, GEMM_BF16X6 = 0, 1
+_PLANES = []     # [(base_ptr, end_ptr, planes tensor (int16 [3, numel]), numel)]
+
+
+def gemm_set_mode(mode: int):
+    check(_L().gct_gemm_set_mode(int(mode)), "gct_gemm_set_mode")
+
+
+def gemm_get_mode() -> int:
+    return _L().gct_gemm_get_mode()
+
+
+def gemm_launch_counts():
+    """(launches of the fp32-MFMA tile kernels, launches of the bf16x6 kernels) since load."""
+    import ctypes
+    out = (ctypes.c_int64 * 2)()
+    check(_L().gct_gemm_launch_counts(ctypes.cast(out, ctypes.c_void_p)), "gct_gemm_launch_counts")
+    return int(out[0]), int(out[1])
+
+
+def split_planes(flat: torch.Tensor, planes: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """flat fp32 [numel] -> int16 [3, numel] holding the hi / mid / lo bf16 pieces of every element
+    (exact: hi + mid + lo == x).  numel % 4 == 0."""
+    _chk(flat, "flat")
+    n = flat.numel()
+    if planes is None:
+        planes = torch.empty(3, n, dtype=torch.int16, device=flat.device)
+    check(_L().gct_split_planes(_p(flat), n, _p(planes), planes.stride(0), _st()), "gct_split_planes")
+    return planes
+
+
+def _drop_planes(base: int, end: int):
+    _PLANES[:] = [e for e in _PLANES if e[1] <= base or e[0] >= end]
+
+
+def register_planes(flat: torch.Tensor, planes: torch.Tensor):
+    """Weights that live inside `flat` are looked up in `planes` by linear_fwd / linear_dgrad.
+    The registration dies with the `flat` tensor object (its address range may be handed to other
+    tensors by the caching allocator afterwards) and replaces anything it overlaps."""
+    base, end = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+    known = any(e[0] == base and e[1] == end and e[4]() is flat for e in _PLANES)
+    _drop_planes(base, end)
+    _PLANES.append((base, end, planes, flat.numel(), weakref.ref(flat)))
+    if not known:
+        weakref.finalize(flat, _drop_planes, base, end)
+
+
+def unregister_planes(flat: torch.Tensor):
+    _drop_planes(flat.data_ptr(), flat.data_ptr() + flat.numel() * 4)
+
+
+def _plane_ptr(ws_):
+    """(pointer to plane 0 of ws_[0], plane stride) if every segment lies in one registered buffer."""
+    if not _PLANES:
+        return None, 0
+    a = ws_[0].data_ptr()
+    for base, end, planes, numel, ref in _PLANES:
+        if base <= a < end:
+            if ref() is None:
+                return None, 0
+            if all(base <= w.data_ptr() < end for w in ws_[1:]):
+                return planes.data_ptr() + (a - base) // 2, planes.stride(0)
+            return None, 0
+    return None, 0
+
+
 def linear_fwd(x2d, ws_: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Tensor]],
                outs: Sequence[torch.Tensor], ldy: int, epi=EPI_BIAS, resid=None, pre=None,
                p=0.0, seed=0, site=0, splitk_ws: Optional[torch.Tensor] = None):
@@ -193,10 +261,12 @@ def linear_fwd(x2d, ws_: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Ten
                                      _p(resid), _p(pre), p, seed, site, _p(splitk_ws), _st()),
               "gct_linear_fwd_ws")
         return
+    wp, pstride = _plane_ptr(ws_)
     with _Timed("gemm_fwd", 2.0 * M * K * nper * len(ws_)):
-        check(_L().gct_linear_fwd(_p(x2d), x2d.stride(0), M, K, w[0], w[1], w[2], ws_[0].stride(0),
-                                  b[0], b[1], b[2], len(ws_), nper, y[0], y[1], y[2], ldy, epi,
-                                  _p(resid), _p(pre), p, seed, site, _st()), "gct_linear_fwd")
+        check(_L().gct_linear_fwd_p(_p(x2d), x2d.stride(0), M, K, w[0], w[1], w[2], ws_[0].stride(0),
+                                    wp, pstride, b[0], b[1], b[2], len(ws_), nper, y[0], y[1], y[2],
+                                    ldy, epi, _p(resid), _p(pre), p, seed, site, None, _st()),
+              "gct_linear_fwd_p")
 
 
 def linear_dgrad(dys: Sequence[torch.Tensor], lddy: int, M: int, ws_: Sequence[torch.Tensor], dx,
@@ -206,9 +276,10 @@ def linear_dgrad(dys: Sequence[torch.Tensor], lddy: int, M: int, ws_: Sequence[t
     w = _seg3(ws_)
     _wait_pending(dx)
     with _Timed("gemm_dgrad", 2.0 * M * K * nper * len(ws_)):
-        check(_L().gct_linear_dgrad(d[0], d[1], d[2], lddy, M, len(ws_), nper, w[0], w[1], w[2],
-                                    ws_[0].stride(0), K, _p(dx), dx.stride(0), depi, _p(pre), p,
-                                    seed, site, _st()), "gct_linear_dgrad")
+        wp, pstride = _plane_ptr(ws_)
+        check(_L().gct_linear_dgrad_p(d[0], d[1], d[2], lddy, M, len(ws_), nper, w[0], w[1], w[2],
+                                      ws_[0].stride(0), wp, pstride, K, _p(dx), dx.stride(0), depi,
+                                      _p(pre), p, seed, site, _st()), "gct_linear_dgrad_p")
 
 
 def linear_wgrad(dys: Sequence[torch.Tensor], lddy: int, x2d, dws: Sequence[torch.Tensor],

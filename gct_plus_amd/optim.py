@@ -60,6 +60,7 @@ class FusedAdam(torch.optim.Optimizer):
             self._t += 1
             ops.adam_step(flat["pbuf"], self.model.flat_grads(), flat["m"], flat["v"],
                           float(g["lr"]), b1, b2, g["eps"], self._t, self.grad_scale)
+            self.model.invalidate_weight_planes()      # bf16 planes are re-split at the next forward
             step_t = torch.tensor(float(self._t))
             for p in g["params"]:
                 self.state[p]["step"] = step_t

@@ -37,7 +37,7 @@ extern "C" {
 #define GCT_ERR_ARG (-1)  /* bad shape / alignment / null pointer            */
 #define GCT_ERR_HIP (-2)  /* a HIP runtime call failed (launch error)        */
 
-#define GCT_ABI_VERSION 1
+#define GCT_ABI_VERSION 2
 
 int gct_version(void);
 const char* gct_last_error(void);
@@ -122,6 +122,46 @@ int gct_linear_wgrad(const float* dy0, const float* dy1, const float* dy2, int64
                      int64_t M, int nseg, int nper, const float* x, int64_t ldx, int K,
                      float* dw0, float* dw1, float* dw2, int64_t lddw,
                      float* db0, float* db1, float* db2, float* ws, void* stream);
+
+/* ---- GEMM arithmetic mode and pre-split weights ------------------------------------------
+ * The nn.Linear GEMMs (Model/sublayers.py:54-59,64-66,70,81-88) run in one of two modes, both with
+ * fp32 operands, fp32 results and fp32-class error:
+ *   GCT_GEMM_F32    : v_mfma_f32_32x32x2_f32 (fp32 fma chains);
+ *   GCT_GEMM_BF16X6 : every operand element is split EXACTLY into three bf16 values (8+8+8
+ *                     significand bits) and the six leading partial products are accumulated in
+ *                     fp32 by v_mfma_f32_32x32x16_bf16; launches that do not qualify (odd shapes,
+ *                     skinny M, no planes for fwd/dgrad) use the fp32 kernels.
+ * Process-wide; default from the environment (GCT_GEMM_MODE=f32|x6, x6 when unset). */
+#define GCT_GEMM_F32 0
+#define GCT_GEMM_BF16X6 1
+int gct_gemm_set_mode(int mode);
+int gct_gemm_get_mode(void);
+/* diagnostics: out2[0] = launches of the fp32-MFMA tile kernels so far, out2[1] = of the bf16x6 kernels */
+int gct_gemm_launch_counts(int64_t* out2);
+
+/* planes[p*plane_stride + i] = p-th bf16 piece (p = 0 high, 1 middle, 2 low) of src[i], i < numel.
+ * numel % 4 == 0, plane_stride % 4 == 0, plane_stride >= numel; src 16-B aligned.  Run it over the
+ * model's flat parameter buffer once per step: the plane of a weight that starts at element offset o
+ * of the buffer starts at element offset o of every plane. */
+int gct_split_planes(const float* src, int64_t numel, uint16_t* planes, int64_t plane_stride,
+                     void* stream);
+
+/* gct_linear_fwd_ws / gct_linear_dgrad with the weights' bf16 planes: wp0 = plane 0 of w0; the planes
+ * of w1, w2 are addressed as wp0 + (w1 - w0), wp0 + (w2 - w0) (the layout gct_split_planes produces
+ * over a common buffer).  wp0 == NULL, or mode GCT_GEMM_F32: identical to the plain entry points. */
+int gct_linear_fwd_p(const float* x, int64_t ldx, int64_t M, int K,
+                     const float* w0, const float* w1, const float* w2, int64_t ldw,
+                     const uint16_t* wp0, int64_t plane_stride,
+                     const float* b0, const float* b1, const float* b2,
+                     int nseg, int nper, float* y0, float* y1, float* y2, int64_t ldy,
+                     int epi, const float* resid, float* pre, float p, uint64_t seed, uint32_t site,
+                     float* ws, void* stream);
+int gct_linear_dgrad_p(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
+                       int64_t M, int nseg, int nper,
+                       const float* w0, const float* w1, const float* w2, int64_t ldw,
+                       const uint16_t* wp0, int64_t plane_stride, int K,
+                       float* dx, int64_t lddx, int depi, const float* pre, float p, uint64_t seed,
+                       uint32_t site, void* stream);
 
 /* elementwise dropout backward for the GCT_EPI_DROP_RESID sites: dy = dropmask*dout/(1-p) */
 int gct_dropout_bwd(const float* dout, float* dy, int64_t rows, int cols, float p, uint64_t seed,

@@ -344,3 +344,104 @@ def test_small_linear_and_copy_rows(ops):
     assert torch.equal(dst.cpu(), torch.cat([a, c], 1))
     s = ops.add(a.to(DEV), a.to(DEV))
     assert torch.equal(s.cpu(), a + a)
+
+
+# ------------------------------------------------------------------ bf16x6 GEMM mode
+def _bf16_to_f32(t_i16):
+    return (t_i16.to(torch.int32) << 16).view(torch.float32)
+
+
+def test_split_planes_exact(ops):
+    x = torch.cat([rnd(4096, seed=1), rnd(4096, seed=2, scale=1e-6), rnd(4096, seed=3, scale=3e4),
+                   torch.tensor([0.0, -0.0, 1.0, -1.0, 3.1415927, 1e-30, 65504.0, 0.1])]).to(DEV)
+    pl = ops.split_planes(x)
+    h, m, l = (_bf16_to_f32(pl[i]) for i in range(3))
+    assert torch.equal((h + m) + l, x), "hi + mid + lo must reproduce the fp32 value exactly"
+    assert (m.abs() <= h.abs() * 2.0 ** -8 + 1e-45).all() and (l.abs() <= h.abs() * 2.0 ** -16 + 1e-45).all()
+
+
+def _planes_for(ops, ws):
+    """Put the weights back to back in one buffer (as flat.py does) and register its planes."""
+    flat = torch.cat([w.reshape(-1) for w in ws]).to(DEV).contiguous()
+    views, o = [], 0
+    for w in ws:
+        views.append(flat[o:o + w.numel()].view(w.shape))
+        o += w.numel()
+    ops.register_planes(flat, ops.split_planes(flat))
+    return flat, views
+
+
+@pytest.mark.parametrize("M,K,nper,nseg", [(300, 512, 512, 3), (1000, 2048, 512, 1), (4099, 512, 2048, 1),
+                                           (6400, 64, 520, 1), (2048, 512, 256, 2), (96, 128, 1000, 1),
+                                           (3104, 512, 512, 3)])
+def test_linear_bf16x6_vs_fp64(ops, M, K, nper, nseg):
+    """The bf16x6 kernels against fp64 at the tolerances of the fp32-MFMA kernels, and never worse
+    than 2x the fp32 kernels' own error; the launch counter proves which kernels ran."""
+    x = rnd(M, K, seed=1)
+    ws = [rnd(nper, K, seed=10 + s, scale=K ** -0.5) for s in range(nseg)]
+    bs = [rnd(nper, seed=20 + s) for s in range(nseg)]
+    N = nper * nseg
+    W = torch.cat(ws).double()
+    dy = rnd(M, N, seed=3)
+    xg, dyg, bg = x.to(DEV), dy.to(DEV), [b.to(DEV) for b in bs]
+    dys = [dyg[:, s * nper:] for s in range(nseg)]
+    flat, wg = _planes_for(ops, ws)
+    res = {}
+    try:
+        for mode in (ops.GEMM_F32, ops.GEMM_BF16X6):
+            ops.gemm_set_mode(mode)
+            c0 = ops.gemm_launch_counts()
+            y = torch.empty(M, N, device=DEV)
+            ops.linear_fwd(xg, wg, bg, [y[:, s * nper:] for s in range(nseg)], N)
+            dx = torch.empty(M, K, device=DEV)
+            ops.linear_dgrad(dys, N, M, wg, dx)
+            dws = [torch.empty(nper, K, device=DEV) for _ in range(nseg)]
+            dbs = [torch.empty(nper, device=DEV) for _ in range(nseg)]
+            ops.linear_wgrad(dys, N, xg, dws, dbs)
+            c1 = ops.gemm_launch_counts()
+            res[mode] = (y.cpu().double(), dx.cpu().double(), torch.cat(dws).cpu().double(), torch.cat(dbs).cpu().double(),
+                         c1[1] - c0[1])
+    finally:
+        ops.gemm_set_mode(ops.GEMM_BF16X6)
+        ops.unregister_planes(flat)
+    refs = (x.double() @ W.t() + torch.cat(bs).double(), dy.double() @ W, dy.double().t() @ x.double(), dy.double().sum(0))
+    assert res[ops.GEMM_F32][4] == 0
+    x6_launches = res[ops.GEMM_BF16X6][4]
+    big = -(-M // 128) * -(-N // 128) >= 192           # smaller forward launches take the skinny-M kernel
+    expect = (1 if (big and (nseg == 1 or nper % 256 == 0)) else 0) + (1 if N % 32 == 0 else 0) + (1 if M % 32 == 0 else 0)
+    assert x6_launches == expect, (x6_launches, expect)
+    tols = ((2e-5, 2e-5), (5e-5, 5e-5), (1e-4 * math.sqrt(M / 100 + 1), 1e-4), (1e-4 * math.sqrt(M / 100 + 1), 1e-4))
+    for i, what in enumerate(("fwd", "dgrad", "wgrad", "bias grad")):
+        close(res[ops.GEMM_BF16X6][i], refs[i], tols[i][0], tols[i][1], f"bf16x6 {what}")
+        e6 = (res[ops.GEMM_BF16X6][i] - refs[i]).abs().mean().item()
+        e32 = (res[ops.GEMM_F32][i] - refs[i]).abs().mean().item()
+        assert e6 <= 2.0 * e32 + 1e-9, f"{what}: bf16x6 mean error {e6:.3e} vs fp32-MFMA {e32:.3e}"
+
+
+def test_linear_bf16x6_epilogues_and_dropout_masks(ops):
+    """Fused epilogues in bf16x6 mode: same dropout masks as the fp32 kernels (the mask depends on
+    (seed, site, row, col) only), values at the fp32 kernels' tolerance."""
+    M, K, N, p, seed = 640, 512, 2048, 0.1, 99
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    W2 = rnd(K, N, seed=5, scale=0.05)
+    dy = rnd(M, K, seed=6)
+    xg, bg, rg, dyg = x.to(DEV), b.to(DEV), r.to(DEV), dy.to(DEV)
+    flat, (wg, w2g) = _planes_for(ops, [w, W2])
+    out = {}
+    try:
+        for mode in (ops.GEMM_F32, ops.GEMM_BF16X6):
+            ops.gemm_set_mode(mode)
+            y1, pre, y2, dpre = (torch.empty(M, N, device=DEV) for _ in range(4))
+            ops.linear_fwd(xg, [wg], [bg], [y1], N, epi=ops.EPI_GELU_DROP, pre=pre, p=p, seed=seed, site=3)
+            ops.linear_fwd(xg, [wg], [bg], [y2], N, epi=ops.EPI_DROP_RESID, resid=rg, p=p, seed=seed, site=4)
+            ops.linear_dgrad([dyg], K, M, [w2g], dpre, depi=ops.DEPI_GELU_BWD, pre=pre, p=p, seed=seed, site=3)
+            out[mode] = [t.cpu() for t in (y1, pre, y2, dpre)]
+    finally:
+        ops.gemm_set_mode(ops.GEMM_BF16X6)
+        ops.unregister_planes(flat)
+    a, c = out[ops.GEMM_F32], out[ops.GEMM_BF16X6]
+    assert torch.equal(a[0] == 0, c[0] == 0) and torch.equal(a[3] == 0, c[3] == 0)
+    u = x.double() @ w.double().t() + b.double()
+    close(c[1], u, 2e-5, 2e-5, "pre")
+    for i, what in enumerate(("gelu+drop", "pre", "drop+resid", "gelu bwd")):
+        close(c[i], a[i].double(), 5e-5, 1e-4, what)
