@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from .. import engine, ops
-from ..flat import FlatModelMixin
+from ..flat import FlatModelMixin, planes_scope
 from .layers import DecoderLayer, EncoderLayer
 from .modules import Embeddings, Norm, PositionalEncoding, get_clones
 from .vaetf import Linear, _TrunkParams
@@ -98,15 +98,18 @@ class Cvaetf(FlatModelMixin, nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
+    @planes_scope
     def encode(self, src, src_mask, econds=None):
         return self.encoder(src, src_mask, econds)[:3]
 
+    @planes_scope
     def decode(self, trg, z, src_mask, trg_mask, dconds=None):
         x = self.decoder(trg, z, src_mask, trg_mask, dconds)
         if self.get_attn:
             x = x[0]
         return self.out(x)
 
+    @planes_scope
     def forward(self, src, trg, src_mask, trg_mask, econds=None, dconds=None):
         z, mu, log_var = self.encoder(src, src_mask, econds)[:3]
         d_output = self.decoder(trg, z, src_mask, trg_mask, dconds)

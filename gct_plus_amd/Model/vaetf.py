@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import engine, ops
-from ..flat import FlatModelMixin
+from ..flat import FlatModelMixin, planes_scope
 from .layers import DecoderLayer, EncoderLayer
 from .modules import Embeddings, Norm, PositionalEncoding, get_clones
 from .sublayers import Sampler
@@ -116,16 +116,19 @@ class Vaetf(FlatModelMixin, nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
+    @planes_scope
     def encode(self, src, src_mask, econds=None):
         x, _ = self.encoder.trunk(src, src_mask, econds)
         return self.sampler(x)
 
+    @planes_scope
     def decode(self, trg, z, src_mask, trg_mask, dconds=None):
         x = self.decoder(trg, z, src_mask, trg_mask, dconds)
         if self.get_attn:
             x = x[0]
         return self.out(x)
 
+    @planes_scope
     def forward(self, src, trg, src_mask, trg_mask, econds=None, dconds=None):
         x, enc_attn = self.encoder.trunk(src, src_mask, econds)
         z, mu, log_var = self.sampler(x)

@@ -9,6 +9,7 @@ lets the wgrad kernels write gradients in place (engine.GradSink).
 """
 from __future__ import annotations
 
+import functools
 from typing import List
 
 import torch
@@ -22,6 +23,7 @@ class FlatModelMixin:
     the module is moved to a CUDA device (`model.cuda()` in train1.py:102)."""
 
     _gct_flat = None
+    _gct_depth = 0
 
     def _apply(self, fn, *a, **kw):
         out = super()._apply(fn, *a, **kw)
@@ -92,27 +94,19 @@ class FlatModelMixin:
             ops.unregister_planes(f["params"])
 
     def _install_plane_hooks(self):
+        """Trunks called directly (model.encoder(...), model.decoder(...): the sampling scripts)
+        refresh the planes themselves; inside forward / encode / decode (`planes_scope`) they do not."""
         if getattr(self, "_gct_plane_hooks", False):
             return
         self._gct_plane_hooks = True
-        self._gct_in_call = 0
-
-        def top_pre(mod, args):
-            if mod._gct_in_call == 0:
-                mod.refresh_weight_planes()
-            mod._gct_in_call += 1
-
-        def top_post(mod, args, out):
-            mod._gct_in_call = max(0, mod._gct_in_call - 1)
 
         def child_pre(child, args):
-            if self._gct_in_call == 0:      # a trunk called directly (model.encoder(...), sampling)
+            if self._gct_depth == 0:
                 self.refresh_weight_planes()
 
-        self.register_forward_pre_hook(top_pre)
-        self.register_forward_hook(top_post, always_call=True)
         for c in self.children():
             c.register_forward_pre_hook(child_pre)
+
 
     # -- helpers used by the fused optimiser and the data-parallel wrapper ------------------
     def flat_params(self) -> torch.Tensor:
@@ -148,3 +142,19 @@ class FlatModelMixin:
         if self._gct_flat is None:
             raise RuntimeError("model parameters are not flattened: move the model to a ROCm "
                                "device first (model.cuda())")
+
+
+def planes_scope(fn):
+    """Decorator for the top-level entry points (forward / encode / decode): refresh the bf16 weight
+    planes once on entry (the reference calls model.forward directly, Model/forward_propagation1.py,
+    so module hooks would not see it)."""
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        if self._gct_depth == 0:
+            self.refresh_weight_planes()
+        self._gct_depth += 1
+        try:
+            return fn(self, *a, **kw)
+        finally:
+            self._gct_depth -= 1
+    return wrapped

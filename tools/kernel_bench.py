@@ -38,7 +38,10 @@ def gemm_suite(reps, only=None):
             continue
         N = nper * nseg
         x = torch.randn(M, K, device=dev)
-        ws = [torch.randn(nper, K, device=dev) * K ** -0.5 for _ in range(nseg)]
+        wflat = torch.randn(nseg * nper * K, device=dev) * K ** -0.5      # one buffer, as flat.py lays weights out
+        ws = [wflat[s * nper * K:(s + 1) * nper * K].view(nper, K) for s in range(nseg)]
+        if ops.gemm_get_mode() == ops.GEMM_BF16X6:
+            ops.register_planes(wflat, ops.split_planes(wflat))
         bs = [torch.randn(nper, device=dev) for _ in range(nseg)]
         y = torch.empty(M, N, device=dev)
         outs = [y[:, s * nper:] for s in range(nseg)]
