@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgctplus_hip.so")
+LIB_PATH = os.environ.get("GCT_LIB_PATH") or os.path.join(_HERE, "libgctplus_hip.so")   # override: A/B builds
 
 P, I64, I32, F32, U64, U32 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_uint32
 

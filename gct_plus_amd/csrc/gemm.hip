@@ -419,6 +419,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
 //     column (4 rows each), float4 stores of 256 contiguous bytes per 16 lanes (was: 64 scalar
 //     stores per lane behind a per-element switch, 42k cycles per tile).
 // =====================================================================================
+// epilogue stores: 16 B per lane, non-temporal -- the outputs (84-336 MB) are far larger than the L2
+// and are not re-read by this kernel, so they should not evict the operand panels (A/B: +3-7 % on the
+// K = 512 shapes, +1 % on the step; -DGCT_EPI_PLAIN restores ordinary stores)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void epi_store4(float* p, const float (&x)[4]) {
+#ifdef GCT_EPI_PLAIN
+  *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
+#else
+  __builtin_nontemporal_store(f32x4_t{x[0], x[1], x[2], x[3]}, reinterpret_cast<f32x4_t*>(p));
+#endif
+}
+
 struct FastEpi {
   const GemmArgs& g;
   // number of extra float4 reads per patch row this epilogue needs (resid / accumulate / pre_in)
@@ -476,7 +488,7 @@ struct FastEpi {
       } else if (epi == GCT_EPI_GELU_DROP) {
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) x[cc] += bs[cc];
-        *reinterpret_cast<float4*>(g.pre + off) = make_float4(x[0], x[1], x[2], x[3]);
+        epi_store4(g.pre + off, x);
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) x[cc] = keep[cc] ? gct_gelu(x[cc]) * g.keep_scale : 0.f;
       } else if (epi == GCT_EPI_DROP_RESID) {
@@ -495,7 +507,7 @@ struct FastEpi {
         for (int cc = 0; cc < 4; ++cc)
           x[cc] = keep[cc] ? x[cc] * gct_gelu_grad(us[cc]) * g.keep_scale : 0.f;
       }
-      *reinterpret_cast<float4*>(cbase + off) = make_float4(x[0], x[1], x[2], x[3]);
+      epi_store4(cbase + off, x);
     }
   }
 };
