@@ -21,30 +21,30 @@ static void run(int64_t M, int K, int N, int epi) {
   h.resize((size_t)N * K);
   hipMemcpy(w, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
   hipMemset(b, 0, N * 4);
-  gct_split_planes(w, (int64_t)N * K, wp, nullptr);
+  gct_split_planes(w, (int64_t)N * K, wp, (int64_t)N * K, nullptr);
   GemmArgs g = {};
   g.M = M; g.N = N; g.K = K;
   g.a = mkseg(x, nullptr, nullptr); g.lda = K; g.a_nper = INT64_MAX / 4;
   g.b = mkseg(w, nullptr, nullptr); g.ldb = K; g.b_nper = N;
-  g.bp0 = wp;
+  g.bp0 = wp; g.bp_stride = (int64_t)N * K;
   g.c0 = y; g.ldc = N; g.c_nper = N; g.ksplit = K; g.nsplit = 1; g.epi = epi; g.bias0 = b; g.pre = pre; g.resid = pre;
   g.thr = gct_drop_threshold(0.1f); g.keep_scale = 1.f / 0.9f; g.rng = gct_rng_make(1, 2);
   g.stamps = st;
   const int64_t tiles = ((M + 127) / 128) * ((N + 255) / 256);
-  hipFuncSetAttribute((const void*)gemm_x6b_kernel<X6_FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, Y_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_x6_kernel<X6_FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
   for (int rep = 0; rep < 3; ++rep) {
     hipMemset(st, 0, 64 * 8 * 8 * 8);
-    hipLaunchKernelGGL((gemm_x6b_kernel<X6_FWD>), dim3((unsigned)tiles), dim3(256), Y_LDS_BYTES, 0, g);
+    hipLaunchKernelGGL((gemm_x6_kernel<X6_FWD>), dim3((unsigned)tiles), dim3(512), X_LDS_BYTES, 0, g);
     hipDeviceSynchronize();
   }
   std::vector<unsigned long long> hs(64 * 8 * 8);
   hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
   double seg[8] = {0};
-  for (int b = 0; b < 64; ++b) for (int wv = 0; wv < 4; ++wv) for (int i = 0; i < 8; ++i) seg[i] += (double)hs[(b * 8 + wv) * 8 + i] / (64 * 4);
+  for (int wv = 0; wv < 64 * 8; ++wv) for (int i = 0; i < 8; ++i) seg[i] += (double)hs[wv * 8 + i] / (64 * 8);
   double tot = 0; for (int i = 0; i < 8; ++i) tot += seg[i];
-  const char* nm[8] = {"prologue", "k-tile body", "barrier", "-", "pre-epilogue sync", "epilogue(+stores)", "-", "-"};
-  printf("M=%ld K=%d N=%d epi=%d: wave lifetime %.0f cycles, k-tiles %d\n", (long)M, K, N, epi, tot, K / 16);
-  for (int i = 0; i < 6; ++i) printf("   %-18s %9.0f cyc  %5.1f %%   (%.0f per k-tile)\n", nm[i], seg[i], 100 * seg[i] / tot, seg[i] / (K / 16));
+  const char* nm[8] = {"prologue", "first half", "barrier", "second half", "pre-epilogue sync", "epilogue(+stores)", "-", "-"};
+  printf("M=%ld K=%d N=%d epi=%d: wave lifetime %.0f cycles, k-tiles %d\n", (long)M, K, N, epi, tot, K / 32);
+  for (int i = 0; i < 6; ++i) printf("   %-18s %9.0f cyc  %5.1f %%   (%.0f per k-tile)\n", nm[i], seg[i], 100 * seg[i] / tot, seg[i] / (K / 32));
   hipFree(x); hipFree(w); hipFree(b); hipFree(y); hipFree(pre); hipFree(wp); hipFree(st);
 }
 
