@@ -9,8 +9,9 @@ A "step" = forward + CE/KL loss + backward + (RCCL gradient all-reduce) + fused 
 of the configuration BASELINE.json's metric is quoted on (configs[1]): vaetf 6+6 layers,
 d_model 512, 8 heads, d_ff 2048, latent 128, batch 512 per GPU, seq_len 80, dropout 0.1,
 fp32, synthetic MOSES-shaped token batches resident in HBM before the timed region.
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fp32-MFMA forward
-GEMM) timed live with HIP events on its launch stream inside the timed region;
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the forward GEMM: the bf16x6
+kernel by default, the fp32-MFMA kernel under GCT_GEMM_MODE=f32) timed live with HIP events on its
+launch stream inside the timed region;
 `cpu_baseline` times the CPU oracle (port of the reference step) on the host cores at N=1.
 """
 import argparse
