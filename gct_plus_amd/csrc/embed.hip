@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const int64_t* __rest
         v = table[t * d + col];
       }
       v = v * scale + pe[(int64_t)l * d + col];
-      v = gct_pick(bits, e) >= thr ? v * keep_scale : 0.f;
+      v = gct_drop_keep(bits, e, (uint32_t)col, thr) ? v * keep_scale : 0.f;
       out[row * d + col] = v;
     }
   }
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void embed_pe_bwd_kernel(const float* __restri
       for (int e = 0; e < 4; ++e) {
         const int64_t row = gq * 4 + e;
         if (row >= rows) break;
-        const float g = gct_pick(bits, e) >= thr ? dout[row * d + col] * gscale : 0.f;
+        const float g = gct_drop_keep(bits, e, (uint32_t)col, thr) ? dout[row * d + col] * gscale : 0.f;
         const int b = (int)(row / L), l = (int)(row - (int64_t)b * L);
         if (l < n_c) {
           dcond[((int64_t)b * n_c + l) * d + col] = g;

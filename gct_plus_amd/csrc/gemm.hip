@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
           if (row >= g.M) continue;
           float v = acc[i][j][q4 * 4 + e];
           const int64_t off = row * g.ldc + cloc;
-          const bool keep = gct_pick(bits, e) >= g.thr;
+          const bool keep = gct_drop_keep(bits, e, (uint32_t)col, g.thr);
           switch (g.epi) {
             case GCT_EPI_BIAS:
               v += bias;
@@ -462,13 +462,13 @@ struct FastEpi {
                                         int64_t col0, float* cbase, int64_t cloc, float4 bias) const {
     // v[rr] = 4 consecutive columns (col0..col0+3) of row row0+rr; row0 % 4 == 0
     const int epi = g.epi;
-    uint4 bits[4];
+    uint4 bits[2];   // one Philox call per 4 rows x 2 columns (col0 % 4 == 0)
     const bool rng = g.thr != 0u && (epi == GCT_EPI_GELU_DROP || epi == GCT_EPI_DROP_RESID ||
                                      epi == EPI_D0 + GCT_DEPI_GELU_BWD);
     if (rng) {
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc)
-        bits[cc] = gct_drop_bits(g.rng, (uint32_t)(row0 >> 2), (uint32_t)(col0 + cc));
+      for (int cp = 0; cp < 2; ++cp)
+        bits[cp] = gct_drop_bits(g.rng, (uint32_t)(row0 >> 2), (uint32_t)(col0 + 2 * cp));
     }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -480,7 +480,7 @@ struct FastEpi {
       bool keep[4] = {true, true, true, true};
       if (rng) {
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) keep[cc] = gct_pick(bits[cc], rr) >= g.thr;
+        for (int cc = 0; cc < 4; ++cc) keep[cc] = gct_drop_keep(bits[cc >> 1], rr, (uint32_t)cc, g.thr);
       }
       if (epi == GCT_EPI_BIAS) {
 #pragma unroll

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* dout, flo
       const int64_t row = gq * 4 + e;
       if (row < rows) {
         const int64_t o = row * cols + col;
-        dy[o] = gct_pick(bits, e) >= thr ? dout[o] * scale : 0.f;
+        dy[o] = gct_drop_keep(bits, e, (uint32_t)col, thr) ? dout[o] * scale : 0.f;
       }
     }
   }
