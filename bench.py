@@ -171,7 +171,7 @@ def main():
                 # ceiling of the kernel is the dense bf16 peak / 6
                 peak = PEAK_BF16_MFMA_TFLOPS / 6.0
                 roof = {"kernel": "gemm_x6_kernel<FWD> (nn.Linear forward, exact 3-way bf16 split of both fp32 "
-                                  "operands, 6 partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
+                                  "operands, 6 partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulate)",
                         "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": round(peak, 1),
                         "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / peak, 4),
                         "traffic": traffic, "avg_launch_us": kern[dom]["avg_us"],

@@ -516,6 +516,8 @@ struct FastEpi {
 // Per-wave epilogue shared by the 128x128 fp32-MFMA kernel and the bf16x6 kernels (both leave a
 // 64x64 block per wave in the 32x32 MFMA accumulator layout): transpose through LDS (stg: 64x64
 // floats private to the wave), then every lane finishes 4 patches of 4 rows x 4 columns.
+__device__ __forceinline__ void wave_epilogue_tail(const GemmArgs& g, float* stg, int lane, int64_t mw,
+                                                   int64_t nw, unsigned z);
 __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][2], float* stg,
                                               int lane, int64_t mw, int64_t nw, unsigned z) {
   {
@@ -528,6 +530,12 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, const f32x16 (&
         for (int r = 0; r < 16; ++r)
           stg[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + c32] = acc[i][j][r];
   }
+  wave_epilogue_tail(g, stg, lane, mw, nw, z);
+}
+
+// second part of the per-wave epilogue: the 64x64 block is in `stg` (row-major, this wave's own LDS writes)
+__device__ __forceinline__ void wave_epilogue_tail(const GemmArgs& g, float* stg, int lane, int64_t mw,
+                                                   int64_t nw, unsigned z) {
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes are visible to it
   __builtin_amdgcn_wave_barrier();
   const FastEpi ep{g};

@@ -144,6 +144,99 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const float* __restrict
 }
 
 
+
+// ---- v0 with v_mfma_f32_16x16x32_bf16 (A/B test of the MFMA shape: same tile, same staging, same loop)
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int lds_off16(int r, int c) {
+  const int g = (0x78 >> (2 * ((r >> 2) & 3))) & 3;     // {0,2,3,1}: conflict-free for the 16x16x32 row reads
+  return r * 64 + ((c ^ g) << 4);
+}
+__global__ __launch_bounds__(256, 2) void gemm_x6_v0_16_kernel(const float* __restrict__ A, const unsigned short* __restrict__ Wp,
+                                                               float* __restrict__ C, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[6 * 8192];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
+  const int tiles_n = N / 128;
+  const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
+  const int64_t plane = (int64_t)N * K;
+  const int a_c4 = t & 7, a_r = t >> 3;
+  const int b_c = t & 3, b_r = t >> 2;
+  const float* ag = A + (int64_t)(bm * 128 + a_r) * K + a_c4 * 4;
+  const unsigned short* bg = Wp + (int64_t)(bn * 128 + b_r) * K + b_c * 8;
+  float4 pa[4];
+  u32x4 pb[3][2];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pa[j] = *reinterpret_cast<const float4*>(ag + (int64_t)j * 32 * K + k0);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) pb[p][j] = *reinterpret_cast<const u32x4*>(bg + p * plane + (int64_t)j * 64 * K + k0);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned h0, m0, l0, h1, m1, l1;
+      split_pair(pa[j].x, pa[j].y, h0, m0, l0);
+      split_pair(pa[j].z, pa[j].w, h1, m1, l1);
+      const int off = lds_off16(a_r + 32 * j, a_c4 >> 1) + (a_c4 & 1) * 8;
+      *reinterpret_cast<u32x2*>(lds + 0 * 8192 + off) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(lds + 1 * 8192 + off) = u32x2{m0, m1};
+      *reinterpret_cast<u32x2*>(lds + 2 * 8192 + off) = u32x2{l0, l1};
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        *reinterpret_cast<u32x4*>(lds + (3 + p) * 8192 + lds_off16(b_r + 64 * j, b_c)) = pb[p][j];
+  };
+  f32x4v acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  gload(0);
+  lstore();
+  __syncthreads();
+  const int fr = l & 15, fc = l >> 4;
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    const bool more = k0 + 32 < K;
+    if (more) gload(k0 + 32);
+    bf16x8 fa[4][3], fb[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        fa[i][p] = *reinterpret_cast<const bf16x8*>(lds + p * 8192 + lds_off16(64 * wm + 16 * i + fr, fc));
+        fb[i][p] = *reinterpret_cast<const bf16x8*>(lds + (3 + p) * 8192 + lds_off16(64 * wn + 16 * i + fr, fc));
+      }
+#define MFMA16(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        MFMA16(fa[i][2], fb[j][0], acc[i][j]);
+        MFMA16(fa[i][0], fb[j][2], acc[i][j]);
+        MFMA16(fa[i][1], fb[j][1], acc[i][j]);
+        MFMA16(fa[i][1], fb[j][0], acc[i][j]);
+        MFMA16(fa[i][0], fb[j][1], acc[i][j]);
+        MFMA16(fa[i][0], fb[j][0], acc[i][j]);
+      }
+    __syncthreads();
+    if (more) lstore();
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = bm * 128 + 64 * wm + 16 * i + fc * 4 + r;
+        const int col = bn * 128 + 64 * wn + 16 * j + fr;
+        C[(int64_t)row * N + col] = acc[i][j][r];
+      }
+}
+
 // ---- v1: 128x256x32 tile, 8 waves (2x4 of 64x64), double-buffered LDS (2 x 72 KB), one barrier per K-tile
 constexpr int STAGE = 72 * 1024, A_PLANE = 8192, B_PLANE = 16384;
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void
@@ -344,7 +437,16 @@ static void run(int M, int K, int N) {
   hipMemset(c, 0, (size_t)M * N * 4);
   const unsigned tiles1 = (M / 128) * (N / 256);
   const double us = time_it([&] { hipLaunchKernelGGL(gemm_x6_v1_kernel, dim3(tiles1), dim3(512), 2 * STAGE, 0, a, wp, c, M, N, K); });
-  printf("v0 %.1f us %.1f TF | ", us0, 2.0 * M * K * N / us0 * 1e-6);
+  const double us16 = time_it([&] { hipLaunchKernelGGL(gemm_x6_v0_16_kernel, dim3(tiles), dim3(256), 0, 0, a, wp, c, M, N, K); });
+  {   // spot-check the 16x16x32 variant against the 32x32x16 one
+    std::vector<float> c16(256), c32(256);
+    hipMemcpy(c16.data(), c + (int64_t)777 * N, 256 * 4, hipMemcpyDeviceToHost);
+    hipLaunchKernelGGL(gemm_x6_kernel, dim3(tiles), dim3(256), 0, 0, a, wp, c, M, N, K);
+    hipMemcpy(c32.data(), c + (int64_t)777 * N, 256 * 4, hipMemcpyDeviceToHost);
+    double md = 0; for (int i = 0; i < 256; ++i) md = std::fmax(md, std::fabs((double)c16[i] - c32[i]));
+    printf("[16x16x32 vs 32x32x16 max diff %.2e] ", md);
+  }
+  printf("v0 %.1f us %.1f TF | v0/16x16x32 %.1f us %.1f TF | ", us0, 2.0 * M * K * N / us0 * 1e-6, us16, 2.0 * M * K * N / us16 * 1e-6);
   // error vs fp64 on a sample, beside the fp32 fmaf chain
   const int ns = 4096;
   std::vector<int> rows(ns), cols(ns);
