@@ -64,6 +64,7 @@ struct GemmArgs {
   GctRng rng;
   float* bias_slab;  // wgrad fast path: per-split column sums of dY, [nsplit][M] (nullptr: off)
   int stagger;       // s_sleep(127) repeats for the second resident workgroup of each CU
+  int64_t row_base;  // rows in front of this launch's row 0 (a launch on a row range keeps the dropout coordinates)
   const uint16_t* bp0;  // bf16x6 kernels: pre-split planes of the B operand (same element offsets as b)
   int64_t bp_stride;    // elements between the hi / mid / lo planes
 #ifdef GCT_STAMPS
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
         const bool need_rng = g.thr != 0u && (g.epi == GCT_EPI_GELU_DROP ||
                                               g.epi == GCT_EPI_DROP_RESID ||
                                               g.epi == EPI_D0 + GCT_DEPI_GELU_BWD);
-        if (need_rng) bits = gct_drop_bits(g.rng, (uint32_t)(row_base >> 2), (uint32_t)col);
+        if (need_rng) bits = gct_drop_bits(g.rng, (uint32_t)((row_base + g.row_base) >> 2), (uint32_t)col);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int64_t row = row_base + e;
@@ -468,7 +469,7 @@ struct FastEpi {
     if (rng) {
 #pragma unroll
       for (int cp = 0; cp < 2; ++cp)
-        bits[cp] = gct_drop_bits(g.rng, (uint32_t)(row0 >> 2), (uint32_t)(col0 + 2 * cp));
+        bits[cp] = gct_drop_bits(g.rng, (uint32_t)((row0 + g.row_base) >> 2), (uint32_t)(col0 + 2 * cp));
     }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -983,6 +984,73 @@ bool fast_ok(const GemmArgs& g, bool vec) {
          (!g.pre_in || gct_aligned16(g.pre_in)) && 130 * g.lda < (1ll << 31) && 130 * g.ldb < (1ll << 31);
 }
 
+// Tail balancing for the bf16x6 forward / dgrad launches (one 128x256 workgroup per CU, 256 CUs): when the
+// tile count leaves a partial last round, the rows of that round are computed as a second launch with K
+// split s ways (s * rem workgroups of 1/s duration) into fp32 slabs, and a small fix-up kernel sums the slabs
+// and applies the epilogue.  E.g. 640 tiles (N = 512 at 40 960 rows): 3 rounds -> 2.5; 2 592 tiles (N = 2 048
+// at 41 472 rows): 11 rounds -> 10.25.  Deterministic (fixed summation order, no atomics).
+float* x6_tail_ws(size_t bytes) {
+  static float* buf = nullptr;
+  static size_t cap = 0;
+  if (bytes > cap) {
+    if (buf) (void)hipFree(buf);
+    buf = nullptr; cap = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&buf), bytes) != hipSuccess) return nullptr;
+    cap = bytes;
+  }
+  return buf;
+}
+
+template <int MODE>
+int launch_x6_tail_split(const GemmArgs& g, hipStream_t st) {
+  constexpr int64_t CUS = 256;
+  static const bool off = getenv("GCT_X6_NO_TAIL_SPLIT") != nullptr;
+  const int64_t tm = (g.M + XBM - 1) / XBM, tn = (g.N + XBN - 1) / XBN, tiles = tm * tn;
+  const int64_t rem = tiles % CUS;
+  if (off || MODE == X6_WGRAD || g.nsplit != 1 || tiles <= CUS || rem == 0 || rem % tn != 0)
+    return launch_x6<MODE>(g, st);
+  const int64_t nkt = g.K / XBK;
+  int best = 1;
+  double cost = 1.0;                                   // duration of the last round, in rounds
+  // a workgroup costs (o + K-tiles) with o ~ 3.3 K-tile times of prologue + epilogue (s_memtime stamps),
+  // so a 1/s share of K costs (o + nkt / s) / (o + nkt) of a full tile, not 1/s
+  const double o = 3.3;
+  for (int s2 = 2; s2 <= 8 && nkt / s2 >= 2; ++s2) {
+    const double c = (double)((rem * s2 + CUS - 1) / CUS) * (o + (double)nkt / s2) / (o + nkt) + 0.05;  // + fix-up pass
+    if (c < cost - 1e-9) { cost = c; best = s2; }
+  }
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (best == 1 || cost > 0.75 || hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+    return launch_x6<MODE>(g, st);
+  const int64_t m1 = (tiles - rem) / tn * XBM, m2 = g.M - m1;
+  float* ws = x6_tail_ws((size_t)best * m2 * g.N * sizeof(float));
+  if (!ws) return launch_x6<MODE>(g, st);
+  GemmArgs head = g;
+  head.M = m1;
+  int rc = launch_x6<MODE>(head, st);
+  if (rc) return rc;
+  GemmArgs e = g;                                      // the tail rows as their own problem
+  e.M = m2; e.row_base = g.row_base + m1;
+  e.a.p0 += m1 * g.lda;                                // FWD / DGRAD: A is [M][K]
+  e.c0 += m1 * g.ldc;
+  if (e.resid) e.resid += m1 * g.ldc;
+  if (e.pre) e.pre += m1 * g.ldc;
+  if (e.pre_in) e.pre_in += m1 * g.ldc;
+  GemmArgs p = e;
+  p.nsplit = best;
+  p.ksplit = ((nkt + best - 1) / best) * XBK;
+  p.nsplit = (int)((g.K + p.ksplit - 1) / p.ksplit);
+  p.epi = EPI_SLAB; p.c0 = ws; p.ldc = g.N; p.slab_stride = m2 * g.N;
+  p.c_d1 = p.c_d2 = 0; p.c_nper = INT64_MAX / 4; p.bias0 = nullptr; p.resid = nullptr; p.pre = nullptr; p.pre_in = nullptr;
+  rc = launch_x6<MODE>(p, st);
+  if (rc) return rc;
+  const int64_t patches = ((m2 + 3) / 4) * (g.N / 4);
+  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((patches + 255) / 256)), dim3(256), 0, st, e,
+                     (const float*)ws, p.nsplit, p.slab_stride);
+  GCT_LAUNCH_CHECK("x6 tail fix-up");
+  return GCT_OK;
+}
+
 template <bool A_KC, bool B_KC>
 int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullptr) {
   const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.nsplit;
@@ -1028,7 +1096,7 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
     constexpr int MODE = A_KC ? (B_KC ? X6_FWD : X6_DGRAD) : X6_WGRAD;
     if ((A_KC || !B_KC) && x6_ok<MODE>(g, vec)) {
       ++g_gemm_launches[1];
-      return launch_x6<MODE>(g, st);
+      return launch_x6_tail_split<MODE>(g, st);
     }
   }
   ++g_gemm_launches[0];
