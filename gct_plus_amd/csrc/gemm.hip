@@ -989,27 +989,15 @@ bool fast_ok(const GemmArgs& g, bool vec) {
 // split s ways (s * rem workgroups of 1/s duration) into fp32 slabs, and a small fix-up kernel sums the slabs
 // and applies the epilogue.  E.g. 640 tiles (N = 512 at 40 960 rows): 3 rounds -> 2.5; 2 592 tiles (N = 2 048
 // at 41 472 rows): 11 rounds -> 10.25.  Deterministic (fixed summation order, no atomics).
-float* x6_tail_ws(size_t bytes) {
-  static float* buf = nullptr;
-  static size_t cap = 0;
-  if (bytes > cap) {
-    if (buf) (void)hipFree(buf);
-    buf = nullptr; cap = 0;
-    if (hipMalloc(reinterpret_cast<void**>(&buf), bytes) != hipSuccess) return nullptr;
-    cap = bytes;
-  }
-  return buf;
-}
-
-template <int MODE>
-int launch_x6_tail_split(const GemmArgs& g, hipStream_t st) {
+// decides whether (and how) a [M][N] x K bf16x6 forward / dgrad launch is tail-split: returns the number of
+// K-splits (1 = no) and the first tail row
+int x6_tail_plan(int64_t M, int64_t N, int64_t K, int64_t* m1_out) {
   constexpr int64_t CUS = 256;
   static const bool off = getenv("GCT_X6_NO_TAIL_SPLIT") != nullptr;
-  const int64_t tm = (g.M + XBM - 1) / XBM, tn = (g.N + XBN - 1) / XBN, tiles = tm * tn;
+  const int64_t tm = (M + XBM - 1) / XBM, tn = (N + XBN - 1) / XBN, tiles = tm * tn;
   const int64_t rem = tiles % CUS;
-  if (off || MODE == X6_WGRAD || g.nsplit != 1 || tiles <= CUS || rem == 0 || rem % tn != 0)
-    return launch_x6<MODE>(g, st);
-  const int64_t nkt = g.K / XBK;
+  if (off || tiles <= CUS || rem == 0 || rem % tn != 0 || K % XBK != 0) return 1;
+  const int64_t nkt = K / XBK;
   int best = 1;
   double cost = 1.0;                                   // duration of the last round, in rounds
   // a workgroup costs (o + K-tiles) with o ~ 3.3 K-tile times of prologue + epilogue (s_memtime stamps),
@@ -1019,12 +1007,21 @@ int launch_x6_tail_split(const GemmArgs& g, hipStream_t st) {
     const double c = (double)((rem * s2 + CUS - 1) / CUS) * (o + (double)nkt / s2) / (o + nkt) + 0.05;  // + fix-up pass
     if (c < cost - 1e-9) { cost = c; best = s2; }
   }
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (best == 1 || cost > 0.75 || hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+  if (best == 1 || cost > 0.75) return 1;
+  *m1_out = (tiles - rem) / tn * XBM;
+  return best;
+}
+
+template <int MODE>
+int launch_x6_tail_split(const GemmArgs& g, hipStream_t st, float* ws, int64_t ws_bytes) {
+  if (MODE == X6_WGRAD || g.nsplit != 1 || !ws || !gct_aligned16(ws)) return launch_x6<MODE>(g, st);
+  int64_t m1 = 0;
+  const int best = x6_tail_plan(g.M, g.N, g.K, &m1);
+  const int64_t m2 = g.M - m1, nkt = g.K / XBK;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;   // keep captured graphs to one kernel per GEMM
+  if (best == 1 || (int64_t)best * m2 * g.N * (int64_t)sizeof(float) > ws_bytes ||
+      hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
     return launch_x6<MODE>(g, st);
-  const int64_t m1 = (tiles - rem) / tn * XBM, m2 = g.M - m1;
-  float* ws = x6_tail_ws((size_t)best * m2 * g.N * sizeof(float));
-  if (!ws) return launch_x6<MODE>(g, st);
   GemmArgs head = g;
   head.M = m1;
   int rc = launch_x6<MODE>(head, st);
@@ -1052,7 +1049,7 @@ int launch_x6_tail_split(const GemmArgs& g, hipStream_t st) {
 }
 
 template <bool A_KC, bool B_KC>
-int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullptr) {
+int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullptr, int64_t ws_bytes = 0) {
   const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.nsplit;
   if (tiles <= 0) return GCT_OK;
   if (tiles > INT_MAX) {
@@ -1096,7 +1093,7 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
     constexpr int MODE = A_KC ? (B_KC ? X6_FWD : X6_DGRAD) : X6_WGRAD;
     if ((A_KC || !B_KC) && x6_ok<MODE>(g, vec)) {
       ++g_gemm_launches[1];
-      return launch_x6_tail_split<MODE>(g, st);
+      return launch_x6_tail_split<MODE>(g, st, skinny_ws, ws_bytes);
     }
   }
   ++g_gemm_launches[0];
@@ -1188,7 +1185,7 @@ static int linear_fwd_impl(const float* x, int64_t ldx, int64_t M, int K, const 
   g.bp0 = wp0; g.bp_stride = pstride;
   const bool vec = al16(x) && al16(w0) && al16(w1) && al16(w2) && (ldx % 4 == 0) &&
                    (ldw % 4 == 0) && (K % 4 == 0);
-  return launch<true, true>(g, vec, (hipStream_t)stream, ws);
+  return launch<true, true>(g, vec, (hipStream_t)stream, ws, ws ? INT64_MAX : 0);   // ws sized by gct_linear_fwd_ws_bytes
 }
 
 extern "C" int gct_linear_fwd(const float* x, int64_t ldx, int64_t M, int K, const float* w0,
@@ -1246,16 +1243,31 @@ extern "C" int gct_split_planes(const float* src, int64_t numel, uint16_t* plane
 }
 
 extern "C" int64_t gct_linear_fwd_ws_bytes(int64_t M, int K, int Ntot) {
-  // worst case: K/128 slabs of [M][Ntot]; only used for skinny M, so this stays small
-  const int64_t ns = K / (4 * BK) > 0 ? K / (4 * BK) : 1;
-  return ns * M * Ntot * (int64_t)sizeof(float) + 256;
+  const int64_t tiles = ((M + BM - 1) / BM) * (((int64_t)Ntot + BN - 1) / BN);
+  int64_t need = 0;
+  if (tiles < 192) {
+    // skinny M: worst case K/128 slabs of [M][Ntot]
+    const int64_t ns = K / (4 * BK) > 0 ? K / (4 * BK) : 1;
+    need = ns * M * Ntot * (int64_t)sizeof(float);
+  } else {
+    int64_t m1 = 0;                                  // bf16x6 tail balancing: s slabs of the tail rows
+    const int s = x6_tail_plan(M, Ntot, K, &m1);
+    if (s > 1) need = (int64_t)s * (M - m1) * Ntot * (int64_t)sizeof(float);
+  }
+  return need + 256;
+}
+
+extern "C" int64_t gct_linear_dgrad_ws_bytes(int64_t M, int Ntot, int K) {
+  int64_t m1 = 0;
+  const int s = x6_tail_plan(M, K, Ntot, &m1);       // dx is [M][K], reduced over Ntot
+  return (s > 1 ? (int64_t)s * (M - m1) * K * (int64_t)sizeof(float) : 0) + 256;
 }
 
 static int linear_dgrad_impl(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
                              int64_t M, int nseg, int nper, const float* w0, const float* w1,
                              const float* w2, int64_t ldw, int K, float* dx, int64_t lddx,
                              int depi, const float* pre, float p, uint64_t seed, uint32_t site,
-                             void* stream, const uint16_t* wp0, int64_t pstride) {
+                             void* stream, const uint16_t* wp0, int64_t pstride, float* ws) {
   GCT_CHECK_ARG(dy0 && w0 && dx && M >= 0 && K > 0 && nseg >= 1 && nseg <= 3 && nper > 0,
                 "linear_dgrad: bad args");
   GCT_CHECK_ARG(nseg < 2 || (w1 && dy1), "linear_dgrad: missing segment 1");
@@ -1273,7 +1285,7 @@ static int linear_dgrad_impl(const float* dy0, const float* dy1, const float* dy
   g.bp0 = wp0; g.bp_stride = pstride;
   const bool vec = al16(dy0) && al16(dy1) && al16(dy2) && al16(w0) && al16(w1) && al16(w2) &&
                    (lddy % 4 == 0) && (ldw % 4 == 0) && (nper % 4 == 0) && (K % 4 == 0);
-  return launch<true, false>(g, vec, (hipStream_t)stream);
+  return launch<true, false>(g, vec, (hipStream_t)stream, ws, ws ? INT64_MAX : 0);   // ws sized by gct_linear_dgrad_ws_bytes
 }
 
 extern "C" int gct_linear_dgrad(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
@@ -1282,7 +1294,7 @@ extern "C" int gct_linear_dgrad(const float* dy0, const float* dy1, const float*
                                 int depi, const float* pre, float p, uint64_t seed, uint32_t site,
                                 void* stream) {
   return linear_dgrad_impl(dy0, dy1, dy2, lddy, M, nseg, nper, w0, w1, w2, ldw, K, dx, lddx, depi, pre,
-                           p, seed, site, stream, nullptr, 0);
+                           p, seed, site, stream, nullptr, 0, nullptr);
 }
 
 extern "C" int gct_linear_dgrad_p(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
@@ -1290,9 +1302,9 @@ extern "C" int gct_linear_dgrad_p(const float* dy0, const float* dy1, const floa
                                   const float* w2, int64_t ldw, const uint16_t* wp0,
                                   int64_t plane_stride, int K, float* dx, int64_t lddx, int depi,
                                   const float* pre, float p, uint64_t seed, uint32_t site,
-                                  void* stream) {
+                                  float* ws, void* stream) {
   return linear_dgrad_impl(dy0, dy1, dy2, lddy, M, nseg, nper, w0, w1, w2, ldw, K, dx, lddx, depi, pre,
-                           p, seed, site, stream, wp0, plane_stride);
+                           p, seed, site, stream, wp0, plane_stride, ws);
 }
 
 extern "C" int gct_linear_wgrad(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,

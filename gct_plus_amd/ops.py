@@ -265,10 +265,12 @@ def linear_fwd(x2d, ws_: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Ten
               "gct_linear_fwd_ws")
         return
     wp, pstride = _plane_ptr(ws_)
+    need = _L().gct_linear_fwd_ws_bytes(M, K, nper * len(ws_))     # skinny split-K slabs or bf16x6 tail slabs
+    wsb = workspace(need, x2d.device) if need > 256 else None
     with _Timed("gemm_fwd", 2.0 * M * K * nper * len(ws_)):
         check(_L().gct_linear_fwd_p(_p(x2d), x2d.stride(0), M, K, w[0], w[1], w[2], ws_[0].stride(0),
                                     wp, pstride, b[0], b[1], b[2], len(ws_), nper, y[0], y[1], y[2],
-                                    ldy, epi, _p(resid), _p(pre), p, seed, site, None, _st()),
+                                    ldy, epi, _p(resid), _p(pre), p, seed, site, _p(wsb), _st()),
               "gct_linear_fwd_p")
 
 
@@ -280,9 +282,11 @@ def linear_dgrad(dys: Sequence[torch.Tensor], lddy: int, M: int, ws_: Sequence[t
     _wait_pending(dx)
     with _Timed("gemm_dgrad", 2.0 * M * K * nper * len(ws_)):
         wp, pstride = _plane_ptr(ws_)
+        need = _L().gct_linear_dgrad_ws_bytes(M, nper * len(ws_), K)
+        wsb = workspace(need, dx.device) if need > 256 else None
         check(_L().gct_linear_dgrad_p(d[0], d[1], d[2], lddy, M, len(ws_), nper, w[0], w[1], w[2],
                                       ws_[0].stride(0), wp, pstride, K, _p(dx), dx.stride(0), depi,
-                                      _p(pre), p, seed, site, _st()), "gct_linear_dgrad_p")
+                                      _p(pre), p, seed, site, _p(wsb), _st()), "gct_linear_dgrad_p")
 
 
 def linear_wgrad(dys: Sequence[torch.Tensor], lddy: int, x2d, dws: Sequence[torch.Tensor],

@@ -161,7 +161,11 @@ int gct_linear_dgrad_p(const float* dy0, const float* dy1, const float* dy2, int
                        const float* w0, const float* w1, const float* w2, int64_t ldw,
                        const uint16_t* wp0, int64_t plane_stride, int K,
                        float* dx, int64_t lddx, int depi, const float* pre, float p, uint64_t seed,
-                       uint32_t site, void* stream);
+                       uint32_t site, float* ws, void* stream);
+/* ws of gct_linear_dgrad_p (nullable): >= gct_linear_dgrad_ws_bytes(M, nseg*nper, K).  With a workspace the
+ * bf16x6 forward / dgrad launches balance a partial last round of tiles (K-split tail launch + fix-up kernel);
+ * gct_linear_fwd_ws_bytes covers the forward (skinny split-K or tail slabs, whichever the launch would use). */
+int64_t gct_linear_dgrad_ws_bytes(int64_t M, int Ntot, int K);
 
 /* elementwise dropout backward for the GCT_EPI_DROP_RESID sites: dy = dropmask*dout/(1-p) */
 int gct_dropout_bwd(const float* dout, float* dy, int64_t rows, int cols, float p, uint64_t seed,
