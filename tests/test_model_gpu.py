@@ -388,3 +388,51 @@ def test_cond2dec_path_vs_reference(golden_dir):
             continue
         e = fx["grads"][name]
         assert_close(p.grad, e, 1e-5 * float(e.abs().max()) + floor, 1e-3, "grad " + name)
+
+
+def test_weight_planes_follow_the_weights():
+    """bf16x6 mode keeps bf16 pieces of the flat parameter buffer.  They are refreshed on every entry into the
+    model (forward / encode / decode / a trunk called directly), dropped by the fused Adam, and two GEMM modes
+    give the same loss and gradients after the weights were changed behind the model's back."""
+    from gct_plus_amd import ops
+    from gct_plus_amd.Model import forward_propagation
+    from gct_plus_amd.Train.trainer1 import loss_function
+    from gct_plus_amd.optim import FusedAdam
+    m = build("vaetf", dropout=0.0).train()
+    ds = synthetic.make_dataset(8, 20, "vaetf", seed=3)
+    b = to_dev(ds)
+    set_eps(m, torch.randn(8, 20, TINY["latent_dim"], generator=torch.Generator().manual_seed(0)))
+    w = m.decoder.layers[0].ff.linear_1.weight
+    assert ops.gemm_get_mode() == ops.GEMM_BF16X6
+
+    def step_loss():
+        for p in m.parameters():
+            p.grad = None
+        prop, mol, mu, lv, _ = forward_propagation["vaetf"](m, b, PAD, False)
+        ys = b["trg"][:, 1:].contiguous().view(-1)
+        loss = loss_function(0.1, prop, mol, None, ys, mu, lv, False, PAD)[0]
+        loss.backward()
+        return float(loss.detach()), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    l0, g0 = step_loss()
+    assert ops._plane_ptr([w])[0] is not None                 # registered by the forward
+    opt = FusedAdam(m.parameters(), lr=1e-3, model=m)
+    opt.step()
+    assert opt._flat is not None and ops._plane_ptr([w])[0] is None    # the fused Adam invalidated them
+    with torch.no_grad():
+        for p in m.parameters():                              # rewrite the weights behind everybody's back
+            p.mul_(1.03)
+    m.encoder(b["src"], (b["src"] != PAD).unsqueeze(-2), None)     # a trunk called directly refreshes too
+    assert ops._plane_ptr([w])[0] is not None
+    l1, g1 = step_loss()
+    ops.gemm_set_mode(ops.GEMM_F32)
+    try:
+        l2, g2 = step_loss()
+    finally:
+        ops.gemm_set_mode(ops.GEMM_BF16X6)
+    assert abs(l1 - l0) > 1e-3 * abs(l0)                       # the new weights were used ...
+    assert abs(l1 - l2) <= 2e-5 * abs(l2)                      # ... and both arithmetic modes agree on them
+    gmax = max(float(v.abs().max()) for v in g2.values())
+    for n in g2:
+        tol = 1e-5 * float(g2[n].abs().max()) + 2e-6 * gmax
+        assert torch.allclose(g1[n], g2[n], atol=tol, rtol=1e-3), n
