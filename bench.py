@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--all-kernel-timing", action="store_true")
+    ap.add_argument("--no-alt-mode", action="store_true", help="skip the short fp32-MFMA-mode comparison run")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -87,6 +88,7 @@ def main():
     from gct_plus_amd.dp import FlatDataParallel
     from gct_plus_amd.optim import FusedAdam
 
+    main_mode = ops.gemm_get_mode()
     mtype = a.model_type
     vs, vt = synthetic.vocab_sizes(mtype)
     nc = synthetic.n_conds(mtype)
@@ -148,6 +150,28 @@ def main():
         dt = float(tt.item())
     final_loss = float(last.item()) / a.batch
 
+    # the same step with the GEMMs on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32), for reference: a short
+    # second timed region after the headline one (every rank runs it, so the collectives stay matched)
+    alt = None
+    if main_mode == ops.GEMM_BF16X6 and not a.no_alt_mode:
+        ops.gemm_set_mode(ops.GEMM_F32)
+        k2 = max(3, a.steps // 3)
+        for i in range(2):
+            step(a.warmup + a.steps + i)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(k2):
+            step(a.warmup + a.steps + 2 + i)
+        fence()
+        dt2 = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt2 = float(tt.item())
+        ops.gemm_set_mode(main_mode)
+        alt = {"gemm_arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "steps": k2,
+               "ms_per_step": round(dt2 / k2 * 1e3, 3), "value": round(a.batch * world * k2 / dt2, 1)}
+
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = a.batch * world * a.steps / dt
@@ -204,6 +228,8 @@ def main():
             "final_loss_per_sample": round(final_loss, 4),
             "roofline": roof,
         }
+        if alt is not None:
+            out["same_step_fp32_mfma_gemms"] = alt
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
