@@ -6,7 +6,6 @@ Differences that do not change results: masks are built on the device; the three
 scalars cross to the host in ONE transfer instead of three `.item()` syncs; `np.float`
 (removed from NumPy) is not used."""
 import os
-from functools import reduce
 from time import time
 
 import pandas as pd
@@ -101,6 +100,20 @@ def run_epoch(args, model, optimizer, dataloader, current_step, beta, LOG, train
     return history
 
 
+def merge_history(history, world_size, device=None):
+    """Mean over ranks of the per-step RCE / KLD / LOSS series (what the reference computes by writing one CSV
+    per rank and re-reading them on rank 0, trainer1.py:134-151, 237-252): one all-reduce of a [3, steps]
+    tensor; BETA and LR are rank-invariant.  Every rank gets the merged history."""
+    if world_size <= 1:
+        return history
+    t = torch.tensor([history['RCE'], history['KLD'], history['LOSS']], dtype=torch.float64)
+    if device is not None and dist.get_backend() == 'nccl':
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    t = (t / world_size).cpu().tolist()
+    return {'RCE': t[0], 'KLD': t[1], 'LOSS': t[2], 'BETA': list(history['BETA']), 'LR': list(history['LR'])}
+
+
 def train_model(args, model, optimizer, train_loader, valid_loader, rank, world_size, LOG):
     beta = 0
     current_step = (args.start_epoch - 1) * len(train_loader)
@@ -136,13 +149,11 @@ def train_model(args, model, optimizer, train_loader, valid_loader, rank, world_
         if rank == 0:
             LOG.info('Save model...')
             save_checkpoint(args, model, optimizer, os.path.join(args.model_folder, f'model_{epoch}.pt'))
-        if world_size > 1 and rank == 0:
-            for data_type in ('train', 'valid'):
-                his = [pd.read_csv(os.path.join(args.model_folder, f'{data_type}_{epoch}_r{r}.csv'),
-                                   index_col=[0]) for r in range(world_size)]
-                cols = [reduce(lambda x, y: x[[c]] + y[[c]], his) / world_size
-                        for c in ('RCE', 'KLD', 'LOSS')]
-                pd.concat(cols + [his[0]['BETA'], his[0]['LR']], axis=1).to_csv(
-                    os.path.join(args.model_folder, f'{data_type}_{epoch}.csv'))
+        if world_size > 1:
+            dev = next(model.parameters()).device
+            for data_type, his in (('train', train_history), ('valid', valid_history)):
+                merged = merge_history(his, world_size, dev)     # same numbers as the reference's CSV round trip
+                if rank == 0:
+                    pd.DataFrame(merged).to_csv(os.path.join(args.model_folder, f'{data_type}_{epoch}.csv'))
         if world_size > 1:
             dist.barrier()

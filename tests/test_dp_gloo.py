@@ -87,3 +87,26 @@ def test_flat_data_parallel_two_ranks(flat):
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, flat, out), nprocs=world, join=True)
     assert all(out.get(r) for r in range(world))
+
+
+def _merge_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gct_plus_amd.Train.trainer1 import merge_history
+    h = {"RCE": [1.0 + rank, 2.0], "KLD": [0.5, 0.25 * (rank + 1)], "LOSS": [3.0, 4.0 + 2 * rank],
+         "BETA": [0.1, 0.1], "LR": [1e-4, 2e-4]}
+    m = merge_history(h, world)
+    if rank == 0:
+        torch.save(m, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_metrics_merge_two_ranks(tmp_path):
+    """trainer1.py:134-151 / 237-252: rank-0's merged CSV = mean over ranks of RCE/KLD/LOSS per step, BETA and LR
+    from rank 0 -- here through one all-reduce instead of the per-rank CSV round trip."""
+    out = str(tmp_path / "merged.pt")
+    mp.spawn(_merge_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    m = torch.load(out)
+    assert m["RCE"] == [1.5, 2.0] and m["KLD"] == [0.5, 0.375] and m["LOSS"] == [3.0, 5.0]
+    assert m["BETA"] == [0.1, 0.1] and m["LR"] == [1e-4, 2e-4]
