@@ -37,6 +37,7 @@ SIGNATURES = {
     "gct_gemm_set_mode": (I32, [I32]),
     "gct_gemm_get_mode": (I32, []),
     "gct_gemm_launch_counts": (I32, [P]),
+    "gct_gemm_x6_kernel_launches": (I64, []),
     "gct_split_planes": (I32, [P, I64, P, I64, P]),
     "gct_linear_dgrad": (I32, [P, P, P, I64, I64, I32, I32, P, P, P, I64, I32, P, I64, I32, P,
                                F32, U64, U32, P]),

@@ -811,6 +811,7 @@ gemm_f32_fast_kernel(const GemmArgs g) {
 }
 
 
+int64_t g_x6_kernel_launches = 0;   // gemm_x6_kernel launches (a tail-balanced call makes two)
 #include "gemm_x6.inc"
 
 // =====================================================================================
@@ -960,7 +961,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs g, 
 // split with six partial products (gemm_x6.inc) wherever a launch qualifies.  Process-wide; the
 // default comes from GCT_GEMM_MODE=f32|x6 (x6 when unset).
 int g_gemm_mode = -1;
-int64_t g_gemm_launches[2] = {0, 0};   // [GCT_GEMM_F32 kernels, bf16x6 kernels] (tests / diagnostics)
+int64_t g_gemm_launches[2] = {0, 0};   // GEMM calls served by [fp32-MFMA kernels, bf16x6 kernels] (tests / diagnostics)
 inline int gemm_mode() {
   if (g_gemm_mode < 0) {
     const char* e = getenv("GCT_GEMM_MODE");
@@ -1223,6 +1224,7 @@ extern "C" int gct_gemm_set_mode(int mode) {
   return GCT_OK;
 }
 extern "C" int gct_gemm_get_mode(void) { return gemm_mode(); }
+extern "C" int64_t gct_gemm_x6_kernel_launches(void) { return g_x6_kernel_launches; }
 extern "C" int gct_gemm_launch_counts(int64_t* out2) {
   GCT_CHECK_ARG(out2, "gemm_launch_counts: null");
   out2[0] = g_gemm_launches[0]; out2[1] = g_gemm_launches[1];

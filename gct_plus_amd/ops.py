@@ -163,6 +163,7 @@ class _Timed:
         self.on = PROFILE is not None and (PROFILE_KINDS is None or self.kind in PROFILE_KINDS)
         if self.on:
             self.c0 = gemm_launch_counts()[1]
+            self.k0 = _L().gct_gemm_x6_kernel_launches()
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
@@ -174,6 +175,8 @@ class _Timed:
             # launches that took the bf16x6 kernels are logged under their own key
             kind = self.kind + "[x6]" if gemm_launch_counts()[1] > self.c0 else self.kind
             PROFILE.setdefault(kind, []).append((self.flops, self.e0, self.e1))
+            PROFILE["_x6_kernel_launches:" + kind] = PROFILE.get("_x6_kernel_launches:" + kind, 0) + \
+                (_L().gct_gemm_x6_kernel_launches() - self.k0)
 
 
 def _seg3(ts: Sequence[Optional[torch.Tensor]]):

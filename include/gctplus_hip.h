@@ -138,6 +138,8 @@ int gct_gemm_set_mode(int mode);
 int gct_gemm_get_mode(void);
 /* diagnostics: out2[0] = launches of the fp32-MFMA tile kernels so far, out2[1] = of the bf16x6 kernels */
 int gct_gemm_launch_counts(int64_t* out2);
+/* diagnostics: gemm_x6_kernel launches so far (a tail-balanced forward / dgrad call launches it twice) */
+int64_t gct_gemm_x6_kernel_launches(void);
 
 /* planes[p*plane_stride + i] = p-th bf16 piece (p = 0 high, 1 middle, 2 low) of src[i], i < numel.
  * numel % 4 == 0, plane_stride % 4 == 0, plane_stride >= numel; src 16-B aligned.  Run it over the
