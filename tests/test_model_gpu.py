@@ -155,6 +155,43 @@ def test_full_size_config_vs_oracle():
         assert_close(p.grad, e, 2e-5 * float(e.abs().max()) + floor, 1e-3, "grad " + name)
 
 
+def test_full_size_pscavaetf_large_batch_vs_oracle():
+    """BASELINE dims, pscavaetf (3 conditions, scaffold prefix), B=96: 7 700+ token rows, so EVERY large GEMM of
+    the step -- forward, dgrad and wgrad, N = 512 / 1024 / 1536 / 2048 -- runs on the bf16x6 kernels (tail-balanced
+    where the tile count asks for it) and is checked against the CPU oracle at the fp32 tolerances."""
+    from oracle import gct_oracle as O
+    from gct_plus_amd import ops
+    mtype, B = "pscavaetf", 96          # 96 x 83 and 96 x 81 token rows: multiples of 32, so wgrad qualifies too
+    model = build(mtype, full=True).train()
+    vs, vt = synthetic.vocab_sizes(mtype)
+    cfg = O.make_cfg(mtype, vs, vt, dropout=0.0, nconds=3, use_cond2lat=True)
+    P = O.make_leaves({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    ds = synthetic.make_dataset(B, max_len=80, model_type=mtype, seed=11)
+    eps = torch.randn(B, 83, 128, generator=torch.Generator().manual_seed(12))
+    set_eps(model, eps)
+    c0 = ops.gemm_launch_counts()
+    prop, mol, mu, lv, z, loss, rce, kld = run_fwd_loss(model, mtype, ds, 0.04)
+    sm, tm, trg_in = O.batch_masks(cfg, ds, PAD)
+    _, omol, omu, olv, oz = O.forward(P, cfg, ds["src"], trg_in, sm, tm, ds["econds"], ds["dconds"], eps=eps, train=True)
+    assert_close(mol, omol, 1e-4, 1e-4, "logits")
+    assert_close(mu, omu, 1e-4, 1e-4, "mu")
+    assert_close(lv, olv, 1e-4, 1e-4, "log_var")
+    assert torch.equal(mol.argmax(-1).cpu(), omol.argmax(-1))
+    ys = ds["trg"][:, 1:].contiguous().view(-1)
+    oloss = O.loss_function(0.04, None, omol, ds["dconds"].unsqueeze(2), ys, omu, olv, False, PAD)[0]
+    assert abs(loss.item() - oloss.item()) <= 2e-5 * abs(oloss.item())
+    loss.backward()
+    c1 = ops.gemm_launch_counts()
+    assert c1[1] - c0[1] >= 190, ("bf16x6 launches", c1[1] - c0[1])     # 67 fwd + 68 dgrad + 68 wgrad qualify
+    oloss.backward()
+    floor = grad_floor(v.grad for v in P.values())
+    for name, p in model.named_parameters():
+        if P[name].grad is None:
+            continue
+        e = P[name].grad
+        assert_close(p.grad, e, 2e-5 * float(e.abs().max()) + floor, 1e-3, "grad " + name)
+
+
 def _args(mtype, d_model):
     nc = synthetic.n_conds(mtype)
     return SimpleNamespace(model_type=mtype, pad_id=PAD, use_cond2dec=False,
