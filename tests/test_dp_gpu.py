@@ -1,6 +1,6 @@
 """Two data-parallel ranks sharing the one GPU of the test box (gloo + host staging for the
-collective; RCCL itself needs >1 GPU and is exercised by `bench.py --gpus N` on the 8-GPU
-node).  Everything else is the production path: HIP forward/backward writing the flat
+collective; real multi-GPU RCCL traffic is exercised by `bench.py --gpus N` on the 8-GPU node; the
+RCCL code path itself runs here with one rank, see the last test).  Everything else is the production path: HIP forward/backward writing the flat
 gradient buffer, FlatDataParallel's end-of-backward averaged all-reduce, FusedAdam.
 Checks: both ranks hold identical parameters after 3 steps, and they equal a single-process
 run over the concatenated global batch with the gradient divided by W (DDP semantics)."""
@@ -97,3 +97,42 @@ def test_two_ranks_match_single_process_global_batch():
             assert torch.allclose(a[k], ref[k], atol=7e-3), k
             continue
         assert torch.allclose(a[k], ref[k], atol=2e-5, rtol=1e-4), k
+
+
+def _nccl_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from gct_plus_amd import synthetic
+    from gct_plus_amd.dp import FlatDataParallel
+    from gct_plus_amd.optim import FusedAdam
+    model = _build(3)
+    ref = _build(3)
+    ddp = FlatDataParallel(model)
+    assert ddp._nccl
+    opt = FusedAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9, model=model)
+    opt_ref = FusedAdam(ref.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9, model=ref)
+    ds = synthetic.make_dataset(24, 20, "pvaetf", seed=5)
+    eps_all = torch.randn(24, 23, 16, generator=torch.Generator().manual_seed(9))
+    for step in range(3):
+        idx = torch.arange(8) + step * 8
+        batch = {k: v[idx].cuda() for k, v in ds.items()}
+        _step_fn("pvaetf", ddp, opt, batch, eps_all[idx])
+        _step_fn("pvaetf", ref, opt_ref, batch, eps_all[idx])
+    torch.cuda.synchronize()
+    ok = all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), ref.state_dict().values()))
+    out["ok"] = bool(ok)
+    out["avg_native"] = bool(ddp._avg_native)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank_path():
+    """The RCCL ('nccl') code path of FlatDataParallel on the one GPU of the test box: process-group creation,
+    ReduceOp.AVG probe, bucket all-reduces launched from the post-accumulate-grad hooks on the autograd thread,
+    waits in the end-of-backward callback.  With one rank the collective is the identity, so three steps must
+    leave exactly the parameters of the unwrapped model."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_nccl_worker, args=(1, _port(), out), nprocs=1, join=True)
+    assert out["ok"], "RCCL-wrapped single rank diverged from the unwrapped model"
