@@ -380,6 +380,7 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
   const uint8_t* flags8 = reinterpret_cast<const uint8_t*>(flags32);
   uint8_t* rowok = reinterpret_cast<uint8_t*>(flags32 + LQP * KG);
   uint8_t* tile_any = rowok + 16 * NT_MAX;
+  uint8_t* rowlive = tile_any + NT_MAX * NT_MAX;   // dO row has a non-zero element
 #ifdef GCT_STAMPS
   unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
@@ -400,8 +401,12 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
   }
   ASTAMP(0);  // staging + flags
   // delta[q] = sum_d dO[q][d] * O[q][d]  (16 lanes per row)
+  // rowlive[q]: the incoming gradient row is not identically zero.  A query tile whose 16 rows are all
+  // zero (padded target positions under an ignore_index loss) contributes exactly nothing: dP = 0,
+  // delta = 0 => dS = 0 => dQ rows = 0 and no dK / dV contribution -- such tiles are skipped below.
   for (int r0 = tid >> 4; r0 < LQP; r0 += BWD_THREADS / 16) {
     float acc = 0.f;
+    int nz = 0;
     if (r0 < a.Lq) {
       const float* orow = a.o_in + ((int64_t)b * a.Lq + r0) * a.ldo + h * DK;
       const float* drow = a.dout + ((int64_t)b * a.Lq + r0) * a.ldo + h * DK;
@@ -409,15 +414,21 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
         const float4 x = *reinterpret_cast<const float4*>(orow + c);
         const float4 y = *reinterpret_cast<const float4*>(drow + c);
         acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+        nz |= (y.x != 0.f) | (y.y != 0.f) | (y.z != 0.f) | (y.w != 0.f);
       }
     }
     acc += __shfl_xor(acc, 8, 64);
     acc += __shfl_xor(acc, 4, 64);
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 1, 64);
+    nz |= __shfl_xor(nz, 8, 64);
+    nz |= __shfl_xor(nz, 4, 64);
+    nz |= __shfl_xor(nz, 2, 64);
+    nz |= __shfl_xor(nz, 1, 64);
     if ((tid & 15) == 0) {
       del_s[r0] = acc;
       lse_s[r0] = r0 < a.Lq ? a.lse_in[((int64_t)b * a.H + h) * a.Lq + r0] : 0.f;
+      rowlive[r0] = (uint8_t)nz;
     }
   }
   __syncthreads();
@@ -431,6 +442,16 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
     if (unit < nqt) {
       // ---- pass A: dQ for query tile u; key index on registers.
       const int u = unit, q = 16 * u + c16;
+      if (!__any(rowlive[q] != 0)) {            // all 16 gradient rows are zero: dQ rows = 0, nothing else
+        if (q < a.Lq) {
+          float* drow = a.dq + ((int64_t)b * a.Lq + q) * a.lddq + h * DK + 4 * g;
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt)
+            *reinterpret_cast<float4*>(drow + 16 * dt) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        ASTAMP(3);
+        continue;
+      }
       const uint32_t use = tiles_for_q(rowok, tile_any, u, nkt, c16);
       f32x4 sacc[NT_MAX], pacc[NT_MAX];
 #pragma unroll
@@ -501,6 +522,7 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
       row_frag<NDT>(bv, Vs, k, g);
 #pragma unroll 1
       for (int u = 0; u < nqt; ++u) {
+        if (!__any(rowlive[16 * u + c16] != 0)) continue;  // zero gradient rows: Pd^T dO = 0 and dS = 0
         const bool ok = __all(rowok[16 * u + c16] != 0);
         if (ok && !tile_any[u * NT_MAX + t]) continue;  // fully masked tile: P = dS = 0
         f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, pa = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -578,7 +600,7 @@ int check_common(const char* who, const float* q, int64_t ldq, const float* k, i
   return GCT_OK;
 }
 
-constexpr size_t MAPS_BYTES = 16 * NT_MAX + NT_MAX * NT_MAX;  // rowok + tile_any
+constexpr size_t MAPS_BYTES = 16 * NT_MAX + NT_MAX * NT_MAX + 16 * NT_MAX;  // rowok + tile_any + (bwd) rowlive
 
 }  // namespace
 
