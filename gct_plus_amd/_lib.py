@@ -43,6 +43,9 @@ SIGNATURES = {
                                F32, U64, U32, P]),
     "gct_linear_wgrad": (I32, [P, P, P, I64, I64, I32, I32, P, I64, I32, P, P, P, I64, P, P, P,
                                P, P]),
+    "gct_nonzero_row_tiles": (I32, [P, I64, I64, I32, P, P, P, P]),
+    "gct_linear_wgrad_kt": (I32, [P, P, P, I64, I64, I32, I32, P, I64, I32, P, P, P, I64, P, P, P,
+                                  P, P, P, P]),
     "gct_dropout_bwd": (I32, [P, P, I64, I32, F32, U64, U32, P]),
     "gct_attn_fwd": (I32, [P, I64, P, I64, P, I64, P, I64, I64, P, I64, P, P, I32, I32, I32, I32,
                            I32, F32, F32, U64, U32, P]),

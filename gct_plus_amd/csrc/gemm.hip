@@ -65,6 +65,8 @@ struct GemmArgs {
   float* bias_slab;  // wgrad fast path: per-split column sums of dY, [nsplit][M] (nullptr: off)
   int stagger;       // s_sleep(127) repeats for the second resident workgroup of each CU
   int64_t row_base;  // rows in front of this launch's row 0 (a launch on a row range keeps the dropout coordinates)
+  const int32_t* kt_list;   // bf16x6 wgrad: ascending 32-row K-tile indices to reduce over (nullptr: all)
+  const int32_t* kt_count;  // device scalar: entries of kt_list
   const uint16_t* bp0;  // bf16x6 kernels: pre-split planes of the B operand (same element offsets as b)
   int64_t bp_stride;    // elements between the hi / mid / lo planes
 #ifdef GCT_STAMPS
@@ -1309,10 +1311,11 @@ extern "C" int gct_linear_dgrad_p(const float* dy0, const float* dy1, const floa
                            p, seed, site, stream, wp0, plane_stride, ws);
 }
 
-extern "C" int gct_linear_wgrad(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
-                                int64_t M, int nseg, int nper, const float* x, int64_t ldx, int K,
-                                float* dw0, float* dw1, float* dw2, int64_t lddw, float* db0,
-                                float* db1, float* db2, float* ws, void* stream) {
+static int linear_wgrad_impl(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
+                             int64_t M, int nseg, int nper, const float* x, int64_t ldx, int K,
+                             float* dw0, float* dw1, float* dw2, int64_t lddw, float* db0,
+                             float* db1, float* db2, float* ws, void* stream, const int32_t* kt_list,
+                             const int32_t* kt_count) {
   GCT_CHECK_ARG(dy0 && x && dw0 && ws && M >= 0 && K > 0 && nseg >= 1 && nseg <= 3 && nper > 0,
                 "linear_wgrad: bad args");
   GCT_CHECK_ARG(nseg < 2 || (dy1 && dw1), "linear_wgrad: missing segment 1");
@@ -1330,6 +1333,7 @@ extern "C" int gct_linear_wgrad(const float* dy0, const float* dy1, const float*
   g.slab_stride = Ntot * K;
   g.ksplit = BK; g.nsplit = 1; g.epi = EPI_SLAB;
   const bool use_x6 = gemm_mode() == GCT_GEMM_BF16X6 && x6_ok<X6_WGRAD>(g, vec);
+  if (use_x6 && kt_list && kt_count) { g.kt_list = kt_list; g.kt_count = kt_count; }   // other kernels reduce over every row
   const int splits = wgrad_splits(M, Ntot, K, use_x6);
   int64_t ks = (M + splits - 1) / splits;
   ks = (ks + BK - 1) / BK * BK;
@@ -1356,4 +1360,21 @@ extern "C" int gct_linear_wgrad(const float* dy0, const float* dy1, const float*
   rc = gct_reduce_slabs_seg(ws, g.nsplit, g.slab_stride, dw0, dw1, dw2, (int64_t)nper * K, Ntot * K, st);
   if (rc || !bslab) return rc;
   return gct_reduce_slabs_seg(bslab, g.nsplit, Ntot, db0, db1, db2, nper, Ntot, st);
+}
+
+extern "C" int gct_linear_wgrad(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
+                                int64_t M, int nseg, int nper, const float* x, int64_t ldx, int K,
+                                float* dw0, float* dw1, float* dw2, int64_t lddw, float* db0,
+                                float* db1, float* db2, float* ws, void* stream) {
+  return linear_wgrad_impl(dy0, dy1, dy2, lddy, M, nseg, nper, x, ldx, K, dw0, dw1, dw2, lddw, db0, db1, db2,
+                           ws, stream, nullptr, nullptr);
+}
+
+extern "C" int gct_linear_wgrad_kt(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
+                                   int64_t M, int nseg, int nper, const float* x, int64_t ldx, int K,
+                                   float* dw0, float* dw1, float* dw2, int64_t lddw, float* db0,
+                                   float* db1, float* db2, float* ws, const int32_t* kt_list,
+                                   const int32_t* kt_count, void* stream) {
+  return linear_wgrad_impl(dy0, dy1, dy2, lddy, M, nseg, nper, x, ldx, K, dw0, dw1, dw2, lddw, db0, db1, db2,
+                           ws, stream, kt_list, kt_count);
 }

@@ -168,6 +168,52 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* dout, flo
   }
 }
 
+// flags[t] = 1 iff rows [32 t, 32 t + 32) of x[rows][cols] hold a non-zero element
+__global__ __launch_bounds__(256) void row_tile_flags_kernel(const float* __restrict__ x, int64_t ld, int64_t rows,
+                                                             int cols, uint8_t* __restrict__ flags) {
+  const int64_t r0 = (int64_t)blockIdx.x * 32;
+  const int c4 = cols / 4;
+  int nz = 0;
+  for (int i = threadIdx.x; i < 32 * c4; i += 256) {
+    const int r = i / c4, c = i - r * c4;
+    if (r0 + r < rows) {
+      const float4 v = *reinterpret_cast<const float4*>(x + (r0 + r) * ld + c * 4);
+      nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+    }
+  }
+  nz = __syncthreads_or(nz);
+  if (threadIdx.x == 0) flags[blockIdx.x] = nz ? 1 : 0;
+}
+
+// list[0..count) = ascending indices t with flags[t] != 0 (one workgroup, deterministic order)
+__global__ __launch_bounds__(1024) void compact_flags_kernel(const uint8_t* __restrict__ flags, int ntiles,
+                                                             int32_t* __restrict__ list, int32_t* __restrict__ count) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t0 = 0; t0 < ntiles; t0 += 1024) {
+    const int t = t0 + threadIdx.x;
+    const int f = (t < ntiles && flags[t]) ? 1 : 0;
+    const unsigned long long m = __ballot(f);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (f) list[off + before] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) tot += wsum[w];
+      base += tot;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = base;
+}
+
 inline unsigned grid_for(int64_t work_items, int block = 256, int64_t cap = 4096) {
   int64_t g = (work_items + block - 1) / block;
   if (g < 1) g = 1;
@@ -263,5 +309,23 @@ extern "C" int gct_dropout_bwd(const float* dout, float* dy, int64_t rows, int c
                      (hipStream_t)stream, dout, dy, rows, cols, gct_drop_threshold(p),
                      1.0f / (1.0f - p), gct_rng_make(seed, site));
   GCT_LAUNCH_CHECK("dropout_bwd");
+  return GCT_OK;
+}
+
+extern "C" int gct_nonzero_row_tiles(const float* x, int64_t ld, int64_t rows, int cols, int32_t* list,
+                                     int32_t* count, uint8_t* flags_ws, void* stream) {
+  GCT_CHECK_ARG(x && list && count && flags_ws && rows >= 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 &&
+                    gct_aligned16(x),
+                "nonzero_row_tiles: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t ntiles = (rows + 31) / 32;
+  GCT_CHECK_ARG(ntiles <= INT32_MAX, "nonzero_row_tiles: too many rows");
+  if (ntiles > 0) {
+    hipLaunchKernelGGL(row_tile_flags_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, x, ld, rows, cols, flags_ws);
+    GCT_LAUNCH_CHECK("row_tile_flags");
+  }
+  hipLaunchKernelGGL(compact_flags_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)flags_ws, (int)ntiles, list,
+                     count);
+  GCT_LAUNCH_CHECK("compact_flags");
   return GCT_OK;
 }

@@ -42,6 +42,9 @@ class Run:
         self.p = float(p) if training else 0.0
         self.seed = next_seed() if self.p > 0 else 0
         self._site = 0
+        # decoder backward only: (list, count) of the 32-row token tiles whose incoming gradient is not
+        # identically zero -- the weight-gradient GEMMs over decoder rows reduce over these tiles only
+        self.kt = None
 
     def site(self) -> int:
         self._site += 1
@@ -126,7 +129,7 @@ def mha_bwd(run: Run, m, saved, dy, G: GradSink, dxq_out, depi_q, dxkv_out=None,
     dk = d // H
     Mq, Mk = B * Lq, B * Lk
     g = ops.dropout_bwd(dy, run.p, run.seed, site_o) if (fused and run.p > 0) else dy
-    ops.linear_wgrad([g], d, o, [G(m.out.weight)], [G(m.out.bias)])
+    ops.linear_wgrad([g], d, o, [G(m.out.weight)], [G(m.out.bias)], kt=run.kt)
     do = _empty(Mq, d, dy)
     ops.linear_dgrad([g], d, Mq, [m.out.weight], do)
     if kvb is None:  # self-attention: fused [q|k|v]
@@ -137,7 +140,7 @@ def mha_bwd(run: Run, m, saved, dy, G: GradSink, dxq_out, depi_q, dxkv_out=None,
         segs = [dqkv, dqkv[:, d:], dqkv[:, 2 * d:]]
         ops.linear_wgrad(segs, 3 * d, xq,
                          [G(m.q_linear.weight), G(m.k_linear.weight), G(m.v_linear.weight)],
-                         [G(m.q_linear.bias), G(m.k_linear.bias), G(m.v_linear.bias)])
+                         [G(m.q_linear.bias), G(m.k_linear.bias), G(m.v_linear.bias)], kt=run.kt)
         ops.linear_dgrad(segs, 3 * d, Mq,
                          [m.q_linear.weight, m.k_linear.weight, m.v_linear.weight], dxq_out,
                          depi=depi_q)
@@ -146,7 +149,7 @@ def mha_bwd(run: Run, m, saved, dy, G: GradSink, dxq_out, depi_q, dxkv_out=None,
         dkv = _empty(Mk, 2 * d, dy)
         ops.attn_bwd(qb, kvb, kvb[:, d:], d, 2 * d, 2 * d, mask_u8, o, do, lse, dq, dkv, dkv[:, d:],
                      d, 2 * d, 2 * d, B, H, Lq, Lk, dk, run.p, run.seed, site_p)
-        ops.linear_wgrad([dq], d, xq, [G(m.q_linear.weight)], [G(m.q_linear.bias)])
+        ops.linear_wgrad([dq], d, xq, [G(m.q_linear.weight)], [G(m.q_linear.bias)], kt=run.kt)   # query rows
         ops.linear_wgrad([dkv, dkv[:, d:]], 2 * d, xkv,
                          [G(m.k_linear.weight), G(m.v_linear.weight)],
                          [G(m.k_linear.bias), G(m.v_linear.bias)])
@@ -180,11 +183,11 @@ def ffn_bwd(run: Run, ff, saved, dy, G: GradSink, dx_out, depi):
     M, d = x.shape
     dff = pre.shape[1]
     g = ops.dropout_bwd(dy, run.p, run.seed, site_o) if (fused and run.p > 0) else dy
-    ops.linear_wgrad([g], d, hdn, [G(ff.linear_2.weight)], [G(ff.linear_2.bias)])
+    ops.linear_wgrad([g], d, hdn, [G(ff.linear_2.weight)], [G(ff.linear_2.bias)], kt=run.kt)
     dpre = _empty(M, dff, dy)
     ops.linear_dgrad([g], d, M, [ff.linear_2.weight], dpre, depi=ops.DEPI_GELU_BWD, pre=pre,
                      p=run.p, seed=run.seed, site=site_h)
-    ops.linear_wgrad([dpre], dff, x, [G(ff.linear_1.weight)], [G(ff.linear_1.bias)])
+    ops.linear_wgrad([dpre], dff, x, [G(ff.linear_1.weight)], [G(ff.linear_1.bias)], kt=run.kt)
     ops.linear_dgrad([dpre], dff, M, [ff.linear_1.weight], dx_out, depi=depi)
 
 
@@ -330,6 +333,11 @@ def decoder_trunk_bwd(dec, run: Run, saved, dy, G: GradSink, need_dz=True):
     trg, z2, dconds, site_pe, lsv, x_last, mean, rstd, B, T, Le, Lk, c2d, c2l = saved
     d, nc = dec.d_model, dec.nconds
     g = dy.reshape(B * T, d).clone()
+    # A decoder row whose incoming gradient is zero (padded target positions under the ignore_index loss)
+    # keeps a zero gradient through every layer below: norm, linear, GELU and dropout backward map a zero row
+    # to a zero row, attention gives zero dQ rows for zero dO rows and masked keys receive no dK / dV.  The
+    # weight-gradient GEMMs over decoder rows therefore reduce over the non-zero 32-row tiles only (exact).
+    run.kt = ops.nonzero_row_tiles(g) if (B * T) % 32 == 0 else None
     ops.norm_bwd(g, x_last, dec.norm.alpha, mean, rstd, G(dec.norm.alpha), G(dec.norm.bias), out=g,
                  eps=dec.norm.eps)
     de = _empty(B * Lk, d, g)
@@ -337,6 +345,7 @@ def decoder_trunk_bwd(dec, run: Run, saved, dy, G: GradSink, need_dz=True):
     for layer, sv in zip(reversed(dec.layers), reversed(lsv)):
         g = dec_layer_bwd(run, layer, sv, g, de, first, G)
         first = False
+    run.kt = None
     if len(dec.layers) == 0:
         de.zero_()
     # embedding side

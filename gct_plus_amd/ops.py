@@ -292,8 +292,23 @@ def linear_dgrad(dys: Sequence[torch.Tensor], lddy: int, M: int, ws_: Sequence[t
                                       _p(pre), p, seed, site, _p(wsb), _st()), "gct_linear_dgrad_p")
 
 
+def nonzero_row_tiles(x2d: torch.Tensor):
+    """(list, count): ascending indices of the 32-row tiles of x2d that hold a non-zero element, and their
+    number as a device scalar (no host round trip).  Feed to linear_wgrad(kt=...) for GEMMs whose dY rows are
+    zero wherever x2d's are (the decoder backward under an ignore_index loss)."""
+    _chk(x2d, "x2d")
+    rows, cols = x2d.shape
+    nt = (rows + 31) // 32
+    lst = torch.empty(max(nt, 1), dtype=torch.int32, device=x2d.device)
+    cnt = torch.empty(1, dtype=torch.int32, device=x2d.device)
+    flags = torch.empty(max(nt, 1), dtype=torch.uint8, device=x2d.device)
+    check(_L().gct_nonzero_row_tiles(_p(x2d), x2d.stride(0), rows, cols, _p(lst), _p(cnt), _p(flags), _st()),
+          "gct_nonzero_row_tiles")
+    return lst, cnt
+
+
 def linear_wgrad(dys: Sequence[torch.Tensor], lddy: int, x2d, dws: Sequence[torch.Tensor],
-                 dbs: Sequence[Optional[torch.Tensor]]):
+                 dbs: Sequence[Optional[torch.Tensor]], kt=None):
     M, K = x2d.shape
     nper = dws[0].shape[0]
     nseg = len(dws)
@@ -304,9 +319,10 @@ def linear_wgrad(dys: Sequence[torch.Tensor], lddy: int, x2d, dws: Sequence[torc
     def launch():
         ws = workspace(_L().gct_wgrad_ws_bytes(M, nseg * nper, K), x2d.device)
         with _Timed("gemm_wgrad+bias+reduce", 2.0 * M * K * nper * nseg):
-            check(_L().gct_linear_wgrad(d[0], d[1], d[2], lddy, M, nseg, nper, _p(x2d), x2d.stride(0),
-                                        K, dw[0], dw[1], dw[2], K, db[0], db[1], db[2], _p(ws), _st()),
-                  "gct_linear_wgrad")
+            check(_L().gct_linear_wgrad_kt(d[0], d[1], d[2], lddy, M, nseg, nper, _p(x2d), x2d.stride(0),
+                                           K, dw[0], dw[1], dw[2], K, db[0], db[1], db[2], _p(ws),
+                                           _p(kt[0]) if kt else None, _p(kt[1]) if kt else None, _st()),
+                  "gct_linear_wgrad_kt")
 
     if not SIDE_ENABLED or torch.cuda.is_current_stream_capturing():
         launch()

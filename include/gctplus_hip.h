@@ -169,6 +169,20 @@ int gct_linear_dgrad_p(const float* dy0, const float* dy1, const float* dy2, int
  * gct_linear_fwd_ws_bytes covers the forward (skinny split-K or tail slabs, whichever the launch would use). */
 int64_t gct_linear_dgrad_ws_bytes(int64_t M, int Ntot, int K);
 
+/* Zero-gradient rows.  Under an ignore_index loss the rows of padded target positions carry exactly zero
+ * gradients through the whole decoder backward.  gct_nonzero_row_tiles lists, in ascending order, the 32-row
+ * tiles of x[rows][cols] that hold a non-zero element (list: >= ceil(rows/32) int32; count: device scalar;
+ * flags_ws: >= ceil(rows/32) bytes); gct_linear_wgrad_kt is gct_linear_wgrad reducing only over the listed
+ * token tiles -- exact whenever every dy row outside them is zero (the skipped terms are 0 * x).  The list is
+ * honoured by the bf16x6 kernel; the fp32 kernels reduce over all rows (same result). */
+int gct_nonzero_row_tiles(const float* x, int64_t ld, int64_t rows, int cols, int32_t* list,
+                          int32_t* count, uint8_t* flags_ws, void* stream);
+int gct_linear_wgrad_kt(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
+                        int64_t M, int nseg, int nper, const float* x, int64_t ldx, int K,
+                        float* dw0, float* dw1, float* dw2, int64_t lddw,
+                        float* db0, float* db1, float* db2, float* ws,
+                        const int32_t* kt_list, const int32_t* kt_count, void* stream);
+
 /* elementwise dropout backward for the GCT_EPI_DROP_RESID sites: dy = dropmask*dout/(1-p) */
 int gct_dropout_bwd(const float* dout, float* dy, int64_t rows, int cols, float p, uint64_t seed,
                     uint32_t site, void* stream);

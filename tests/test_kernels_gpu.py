@@ -447,3 +447,35 @@ def test_linear_bf16x6_epilogues_and_dropout_masks(ops, M, N):
     close(c[1], u, 2e-5, 2e-5, "pre")
     for i, what in enumerate(("gelu+drop", "pre", "drop+resid", "gelu bwd")):
         close(c[i], a[i].double(), 5e-5, 1e-4, what)
+
+
+def test_wgrad_over_nonzero_row_tiles(ops):
+    """gct_nonzero_row_tiles + gct_linear_wgrad_kt: reducing only over the 32-row token tiles whose gradient rows
+    are not all zero gives the dense result (the skipped terms are exact zeros)."""
+    M, K, N = 32 * 260, 512, 1024
+    x = rnd(M, K, seed=1).to(DEV)
+    dy = rnd(M, N, seed=2).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    dead = torch.zeros(M, dtype=torch.bool)
+    for s in range(0, M, 81):                       # runs of dead rows like padded target positions
+        ln = int(torch.randint(20, 60, (1,), generator=g))
+        dead[s + ln:s + 81] = True
+    dy[dead.to(DEV)] = 0
+    lst, cnt = ops.nonzero_row_tiles(dy)
+    live_tiles = (~dead.view(-1, 32).all(1)).nonzero().flatten().to(torch.int32)
+    assert int(cnt.item()) == live_tiles.numel() and torch.equal(lst[:live_tiles.numel()].cpu(), live_tiles)
+    assert live_tiles.numel() < M // 32
+    out = {}
+    for name, kt in (("dense", None), ("tiles", (lst, cnt))):
+        dw = torch.empty(N, K, device=DEV)
+        db = torch.empty(N, device=DEV)
+        c0 = ops.gemm_launch_counts()
+        ops.linear_wgrad([dy], N, x, [dw], [db], kt=kt)
+        assert ops.gemm_launch_counts()[1] == c0[1] + 1          # bf16x6 kernel
+        out[name] = (dw.cpu().double(), db.cpu().double())
+    ref_w = dy.double().t().cpu() @ x.double().cpu()
+    ref_b = dy.double().sum(0).cpu()
+    tol = 1e-4 * math.sqrt(M / 100 + 1)
+    close(out["tiles"][0], ref_w, tol, 1e-4, "wgrad over listed tiles")
+    close(out["tiles"][1], ref_b, tol, 1e-4, "bias grad over listed tiles")
+    close(out["tiles"][0], out["dense"][0], 2e-6 * float(ref_w.abs().max()), 1e-5, "listed vs dense (summation split differs)")
