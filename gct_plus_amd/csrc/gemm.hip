@@ -1134,6 +1134,9 @@ inline Seg3 mkseg(const float* p0, const float* p1, const float* p2) {
 
 int gct_reduce_slabs_seg(const float* slabs, int nslab, int64_t stride, float* d0, float* d1,
                          float* d2, int64_t nper_elems, int64_t n, hipStream_t st);
+int gct_reduce_slabs_seg2(const float* sa, int nslab, int64_t stride_a, float* a0, float* a1, float* a2,
+                          int64_t nper_a, int64_t na, const float* sb, int64_t stride_b, float* b0, float* b1,
+                          float* b2, int64_t nper_b, int64_t nb, hipStream_t st);
 int gct_colsum(const float* y0, const float* y1, const float* y2, int64_t ld, int64_t M, int nseg,
                int nper, float* d0, float* d1, float* d2, float* ws, hipStream_t st);
 int64_t gct_colsum_ws_floats(int64_t M, int64_t N);
@@ -1357,9 +1360,10 @@ static int linear_wgrad_impl(const float* dy0, const float* dy1, const float* dy
   }
   int rc = launch<false, false>(g, vec, st);
   if (rc) return rc;
-  rc = gct_reduce_slabs_seg(ws, g.nsplit, g.slab_stride, dw0, dw1, dw2, (int64_t)nper * K, Ntot * K, st);
-  if (rc || !bslab) return rc;
-  return gct_reduce_slabs_seg(bslab, g.nsplit, Ntot, db0, db1, db2, nper, Ntot, st);
+  if (bslab)     // weight and bias slabs in one launch
+    return gct_reduce_slabs_seg2(ws, g.nsplit, g.slab_stride, dw0, dw1, dw2, (int64_t)nper * K, Ntot * K, bslab, Ntot,
+                                 db0, db1, db2, nper, Ntot, st);
+  return gct_reduce_slabs_seg(ws, g.nsplit, g.slab_stride, dw0, dw1, dw2, (int64_t)nper * K, Ntot * K, st);
 }
 
 extern "C" int gct_linear_wgrad(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,

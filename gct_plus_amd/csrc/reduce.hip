@@ -11,14 +11,12 @@ namespace {
 // through LDS in fixed order => deterministic.  SL is picked from n so that even a 2 KB
 // destination (norm / bias partials, up to 1024 slabs) is reduced by many lanes in parallel.
 template <int SL>
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs,
-                                                           int nslab, int64_t stride, float* d0,
-                                                           float* d1, float* d2, int64_t nper,
-                                                           int64_t n4, int accumulate) {
+__device__ __forceinline__ void reduce_slabs_body(float4* red, const float* __restrict__ slabs, int nslab,
+                                                  int64_t stride, float* d0, float* d1, float* d2, int64_t nper,
+                                                  int64_t n4, int accumulate, unsigned bid, unsigned nblk) {
   constexpr int CW = 256 / SL;
-  __shared__ float4 red[256];
   const int c = threadIdx.x % CW, sl = threadIdx.x / CW;
-  for (int64_t base = (int64_t)blockIdx.x * CW; base < n4; base += (int64_t)gridDim.x * CW) {
+  for (int64_t base = (int64_t)bid * CW; base < n4; base += (int64_t)nblk * CW) {
     const int64_t i = base + c;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n4) {
@@ -57,6 +55,33 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
       *reinterpret_cast<float4*>(d) = a;
     }
   }
+}
+
+template <int SL>
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs,
+                                                           int nslab, int64_t stride, float* d0,
+                                                           float* d1, float* d2, int64_t nper,
+                                                           int64_t n4, int accumulate) {
+  __shared__ float4 red[256];
+  reduce_slabs_body<SL>(red, slabs, nslab, stride, d0, d1, d2, nper, n4, accumulate, blockIdx.x, gridDim.x);
+}
+
+// two reductions in one launch (the weight slabs and the bias slabs of a split-K wgrad): blocks [0, ga) take
+// region A with 4 slab lanes, the rest region B with 64 (a 2 KB destination still gets many lanes)
+struct ReduceRegion {
+  const float* slabs;
+  int64_t stride;
+  float *d0, *d1, *d2;
+  int64_t nper, n4;
+};
+__global__ __launch_bounds__(256) void reduce_slabs2_kernel(const ReduceRegion a, const ReduceRegion b, int nslab,
+                                                            unsigned ga) {
+  __shared__ float4 red[256];
+  if (blockIdx.x < ga)
+    reduce_slabs_body<4>(red, a.slabs, nslab, a.stride, a.d0, a.d1, a.d2, a.nper, a.n4, 0, blockIdx.x, ga);
+  else
+    reduce_slabs_body<64>(red, b.slabs, nslab, b.stride, b.d0, b.d1, b.d2, b.nper, b.n4, 0, blockIdx.x - ga,
+                          gridDim.x - ga);
 }
 
 static int launch_reduce(const float* slabs, int nslab, int64_t stride, float* d0, float* d1,
@@ -222,6 +247,32 @@ inline unsigned grid_for(int64_t work_items, int block = 256, int64_t cap = 4096
 }
 
 }  // namespace
+
+int gct_reduce_slabs_seg(const float* slabs, int nslab, int64_t stride, float* d0, float* d1,
+                         float* d2, int64_t nper_elems, int64_t n, hipStream_t st);
+
+// weight slabs (A) + bias slabs (B) of one split-K wgrad in ONE launch; falls back to two launches when a
+// region is not float4-shaped
+int gct_reduce_slabs_seg2(const float* sa, int nslab, int64_t stride_a, float* a0, float* a1, float* a2,
+                          int64_t nper_a, int64_t na, const float* sb, int64_t stride_b, float* b0, float* b1,
+                          float* b2, int64_t nper_b, int64_t nb, hipStream_t st) {
+  auto vec = [](const float* s, int64_t stride, float* d0, float* d1, float* d2, int64_t nper, int64_t n) {
+    return n > 0 && (n % 4 == 0) && (nper % 4 == 0) && (stride % 4 == 0) && gct_aligned16(s) && gct_aligned16(d0) &&
+           (!d1 || gct_aligned16(d1)) && (!d2 || gct_aligned16(d2));
+  };
+  if (!vec(sa, stride_a, a0, a1, a2, nper_a, na) || !vec(sb, stride_b, b0, b1, b2, nper_b, nb)) {
+    int rc = gct_reduce_slabs_seg(sa, nslab, stride_a, a0, a1, a2, nper_a, na, st);
+    if (rc) return rc;
+    return gct_reduce_slabs_seg(sb, nslab, stride_b, b0, b1, b2, nper_b, nb, st);
+  }
+  const ReduceRegion ra = {sa, stride_a, a0, a1, a2, nper_a, na / 4}, rb = {sb, stride_b, b0, b1, b2, nper_b, nb / 4};
+  int64_t ga = (ra.n4 + 63) / 64, gb = (rb.n4 + 3) / 4;
+  if (ga > 8192) ga = 8192;
+  if (gb > 1024) gb = 1024;
+  hipLaunchKernelGGL(reduce_slabs2_kernel, dim3((unsigned)(ga + gb)), dim3(256), 0, st, ra, rb, nslab, (unsigned)ga);
+  GCT_LAUNCH_CHECK("reduce_slabs2");
+  return GCT_OK;
+}
 
 int gct_reduce_slabs_seg(const float* slabs, int nslab, int64_t stride, float* d0, float* d1,
                          float* d2, int64_t nper_elems, int64_t n, hipStream_t st) {

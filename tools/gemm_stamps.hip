@@ -6,6 +6,7 @@
 #include <vector>
 
 int gct_reduce_slabs_seg(const float*, int, int64_t, float*, float*, float*, int64_t, int64_t, hipStream_t) { return 0; }
+int gct_reduce_slabs_seg2(const float*, int, int64_t, float*, float*, float*, int64_t, int64_t, const float*, int64_t, float*, float*, float*, int64_t, int64_t, hipStream_t) { return 0; }
 int gct_colsum(const float*, const float*, const float*, int64_t, int64_t, int, int, float*, float*, float*, float*, hipStream_t) { return 0; }
 int64_t gct_colsum_ws_floats(int64_t, int64_t) { return 0; }
 
