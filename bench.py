@@ -1,123 +1,310 @@
 #!/usr/bin/env python3
 """Headline benchmark: SMILES/s of the vaetf training step on MI355X (BASELINE.json).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            # N = 1, 2, 4, 8 on ONE node
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+
+Started plainly with --gpus N > 1 (no RANK/WORLD_SIZE in the environment) this file is its own
+launcher: the parent process touches no GPU, picks a free rendezvous port on 127.0.0.1 and starts
+N fresh `python bench.py` worker processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
+(one process per GPU, the layout of the reference's train1.py:152-171); rank 0's stdout is the
+parent's stdout, so exactly ONE JSON line comes out.  Under torch.distributed.run the same worker
+code runs directly.
 
 A "step" = forward + CE/KL loss + backward + (RCCL gradient all-reduce) + fused Adam + LR write
 of the configuration BASELINE.json's metric is quoted on (configs[1]): vaetf 6+6 layers,
 d_model 512, 8 heads, d_ff 2048, latent 128, batch 512 per GPU, seq_len 80, dropout 0.1,
-fp32, synthetic MOSES-shaped token batches resident in HBM before the timed region.
+fp32, synthetic MOSES-shaped token batches resident in HBM before the timed region
+(--model-type scavaetf --gpus 8 is configs[3]: global batch 4096).
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the forward GEMM: the bf16x6
 kernel by default, the fp32-MFMA kernel under GCT_GEMM_MODE=f32) timed live with HIP events on its
-launch stream inside the timed region;
-`cpu_baseline` times the CPU oracle (port of the reference step) on the host cores at N=1.
+launch stream inside the timed region; `fixed_len_80` is the same step on a batch without padding
+(every sample 80 tokens: the worst case, none of the zero-row shortcuts apply); `decode` is
+BASELINE configs[4]'s metric (KV-cached greedy decode, decoded SMILES/s); `cpu_baseline` times the
+CPU oracle (port of the reference step) on the host cores at N=1.
+
+--selftest-cpu swaps the HIP model for a few-kB plain-torch stand-in on the CPU so that THIS file's
+launcher, rendezvous, sharding, step loop, fences, max-over-ranks timing and JSON line can be
+driven end to end by `tests/test_bench_launcher.py` with two gloo ranks and no GPU; its line is
+labelled as a self-test and carries no performance claim.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (no sparsity)
-FLOP_PER_SMILES_STEP = 22.09e9    # 3 x 7.363 GFLOP forward (vaetf, S=80, T=81)
+FLOP_PER_SMILES_STEP = {"vaetf": 22.09e9, "scavaetf": 22.09e9,     # 3 x 7.363 GFLOP forward
+                        "pvaetf": 22.58e9, "pscavaetf": 22.58e9}   # 3 x 7.528 (n_c = 3)
 
 
-def cpu_baseline(batch_size=64, steps=3, warm=1, dropout=0.1):
-    """The reference's training step restated on CPU (oracle/gct_oracle.py, pinned to the
-    reference by tests/golden) on config 1: vaetf, B=64, S=80, Adam.  Bounded sample."""
-    from oracle import gct_oracle as O
-    from gct_plus_amd import synthetic
-    # the GPU box gives one GPU's share of the host: 16 cores (not the 128 torch reports)
-    torch.set_num_threads(min(16, os.cpu_count() or 16))
-    cfg = O.make_cfg("vaetf", 28, 30, dropout=dropout, nconds=0, use_cond2lat=True)
-    P = O.make_leaves(O.init_state(cfg, seed=1))
-    opt = O.make_adam(O.trainable(P, cfg))
-    ds = synthetic.make_dataset(batch_size * (steps + warm), 80, "vaetf", seed=0)
-    times = []
-    for i, b in enumerate(synthetic.batches(ds, batch_size)):
-        t0 = time.perf_counter()
-        O.train_step(P, cfg, opt, b, 0.04, synthetic.PAD_ID, i + 1)
-        times.append(time.perf_counter() - t0)
-    t = sum(times[warm:]) / max(1, len(times) - warm)
-    return {"value": round(batch_size / t, 2), "unit": "SMILES/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{steps} steps after {warm} warm-up, vaetf B={batch_size} S=80 dropout {dropout} "
-                      f"Adam, torch {torch.__version__} CPU, {t*1e3:.0f} ms/step"}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (BASELINE configs[1])")
-    ap.add_argument("--model-type", default="vaetf")
+    ap.add_argument("--model-type", default="vaetf", choices=["vaetf", "pvaetf", "scavaetf", "pscavaetf"])
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--fixed-len", action="store_true", help="headline region on unpadded (all 80-token) batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--all-kernel-timing", action="store_true")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the short fp32-MFMA-mode comparison run")
-    a = ap.parse_args()
+    ap.add_argument("--no-fixed-len-leg", action="store_true", help="skip the short fixed_len_80 region")
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode block (configs[4] metric)")
+    ap.add_argument("--decode-n", type=int, default=512)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the product path); gloo only for the launcher tests")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="test rigs with ONE GPU: every rank uses cuda:0 and gradients are exchanged through "
+                         "host memory over gloo (RCCL refuses two ranks on one device)")
+    ap.add_argument("--tiny", action="store_true", help="N=2 d_model=64 d_ff=128 h=4 latent=16 (launcher tests)")
+    ap.add_argument("--selftest-cpu", action="store_true", help="launcher/step-loop self-test on CPU (see docstring)")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------- launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_workers(a, argv):
+    """Parent of a plain `bench.py --gpus N` call.  Touches no GPU (no torch import here): N fresh
+    interpreters, each of which initialises its own device after it has its rank."""
+    port = _free_port()
+    procs = []
+    ncpu = os.cpu_count() or 8
+    for r in range(a.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GCT_BENCH_LAUNCHER="self-spawn")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, ncpu // a.gpus)))
+        # rank 0 owns the parent's stdout (the ONE JSON line); other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = list(procs)
+    while alive:                                   # a dead rank must not leave the others in a collective
+        for p in list(alive):
+            c = p.poll()
+            if c is None:
+                continue
+            alive.remove(p)
+            if c != 0 and rc == 0:
+                rc = c
+                for q in alive:
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------ cpu baseline
+def cpu_baseline(batch_size=64, steps=10, warm=3):
+    """The reference's training step restated on CPU (oracle/gct_oracle.py, pinned to the
+    reference by tests/golden) on config 1: vaetf, B=64, S=80, Adam.  SURVEY.md 8(d): median of
+    >= 10 steps after 3 warm-up, with dropout 0.1 (the headline's setting) and with dropout 0
+    (CPU bernoulli_ is a large share of the CPU step).  Bounded sample: ~26 steps of ~2-3 s."""
+    import statistics
+    import torch
+    from oracle import gct_oracle as O
+    from gct_plus_amd import synthetic
+    # the GPU box gives one GPU's share of the host: 16 cores (not the 128 torch reports)
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
+    res = {}
+    for dropout in (0.1, 0.0):
+        cfg = O.make_cfg("vaetf", 28, 30, dropout=dropout, nconds=0, use_cond2lat=True)
+        P = O.make_leaves(O.init_state(cfg, seed=1))
+        opt = O.make_adam(O.trainable(P, cfg))
+        ds = synthetic.make_dataset(batch_size * (steps + warm), 80, "vaetf", seed=0)
+        times = []
+        for i, b in enumerate(synthetic.batches(ds, batch_size)):
+            t0 = time.perf_counter()
+            O.train_step(P, cfg, opt, b, 0.04, synthetic.PAD_ID, i + 1)
+            times.append(time.perf_counter() - t0)
+        res[dropout] = statistics.median(times[warm:])
+    t = res[0.1]
+    return {"value": round(batch_size / t, 2), "unit": "SMILES/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"median of {steps} steps after {warm} warm-up, vaetf B={batch_size} S=80 dropout 0.1 "
+                      f"Adam, torch {torch.__version__} CPU, {t*1e3:.0f} ms/step",
+            "dropout0": {"value": round(batch_size / res[0.0], 2), "ms_per_step": round(res[0.0] * 1e3)}}
+
+
+# ---------------------------------------------------------------------------------- workloads
+def selftest_workload(a, dev, world, rank):
+    """Plain-torch stand-in (CPU): same batch dict, same FlatDataParallel wrapper, same loop."""
+    import torch
+    import torch.nn as nn
+    from gct_plus_amd import synthetic
+    from gct_plus_amd.dp import FlatDataParallel
+    from gct_plus_amd.flat import FlatModelMixin
+
+    class Stub(FlatModelMixin, nn.Module):
+        def __init__(self, vs, vt):
+            super().__init__()
+            self.emb = nn.Embedding(vs, 16)
+            self.out = nn.Linear(16, vt)
+
+        def forward(self, src, trg):
+            h = self.emb(src).mean(1, keepdim=True).expand(-1, trg.size(1), -1)
+            return self.out(torch.tanh(h))
+
+    if os.environ.get("GCT_BENCH_SELFTEST_DIE") == str(rank):    # launcher test: a rank that dies early
+        sys.exit(3)
+    mtype = a.model_type
+    vs, vt = synthetic.vocab_sizes(mtype)
+    torch.manual_seed(1 + rank)                   # ranks differ until the wrapper's broadcast
+    inner = Stub(vs, vt)
+    inner.flatten_parameters()
+    model = FlatDataParallel(inner) if world > 1 else inner
+    opt = torch.optim.Adam(inner.parameters(), lr=1e-3)
+
+    def fwd_loss(batch):
+        logits = model(batch["src"], batch["trg"][:, :-1])
+        ys = batch["trg"][:, 1:].reshape(-1)
+        return nn.functional.cross_entropy(logits.reshape(-1, vt), ys, ignore_index=synthetic.PAD_ID,
+                                           reduction="sum")
+    return inner, opt, fwd_loss
+
+
+def hip_workload(a, dev, world, rank):
+    import torch
+    from gct_plus_amd import synthetic
+    from gct_plus_amd.Model import forward_propagation, model_dict
+    from gct_plus_amd.Train.trainer1 import loss_function
+    from gct_plus_amd.dp import FlatDataParallel
+    from gct_plus_amd.optim import FusedAdam
+
+    mtype = a.model_type
+    vs, vt = synthetic.vocab_sizes(mtype)
+    nc = synthetic.n_conds(mtype)
+    dims = dict(N=2, d_model=64, dff=128, h=4, latent_dim=16) if a.tiny else \
+        dict(N=6, d_model=512, dff=2048, h=8, latent_dim=128)
+    torch.manual_seed(1)
+    inner = model_dict[mtype](vs, vt, dropout=a.dropout, nconds=nc, use_cond2dec=False, use_cond2lat=True, **dims)
+    inner = inner.to(dev).train()
+    model = inner
+    if world > 1:
+        kw = {}
+        if a.share_gpu:
+            from gct_plus_amd.testing import host_staged_allreduce, host_staged_broadcast
+            kw = dict(allreduce=host_staged_allreduce, broadcast=host_staged_broadcast)
+        model = FlatDataParallel(inner, **kw)
+    opt = FusedAdam(inner.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-9, model=inner)
+    pad_id, beta = synthetic.PAD_ID, 0.04
+
+    def fwd_loss(batch):
+        prop, mol, mu, lv, _ = forward_propagation[mtype](model, batch, pad_id, False)
+        ys = batch["trg"][:, 1:].contiguous().view(-1)
+        ys_cond = batch["dconds"].unsqueeze(2).contiguous().view(-1, nc, 1) if nc else None
+        loss, _, _, _ = loss_function(beta, prop, mol, ys_cond, ys, mu, lv, False, pad_id)
+        return loss
+    return inner, opt, fwd_loss
+
+
+def decode_block(model, a, dev, world, fence, reduce_max):
+    """BASELINE configs[4] metric: decoded SMILES/s of the KV-cached greedy decode (reference loop:
+    Inference/sampling_tool.py:140-184), n sequences per GPU, max_strlen 80 => 79 generated tokens, no
+    early stop (eos never matches: the worst case).  Latent length 40 (+ n_c): the reference draws the
+    latent length from the training-set token-length distribution (MOSES mean ~35-40)."""
+    import torch
+    from gct_plus_amd import synthetic
+    from gct_plus_amd.decode import KVDecoder
+    nc = synthetic.n_conds(a.model_type)
+    n, Le = a.decode_n, 40 + nc
+    lat = model.decoder.fc_z.weight.shape[1]
+    was_training = model.training
+    model.eval()
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(n, Le, lat, generator=g).to(dev)
+    dconds = torch.randn(n, nc, generator=g).to(dev) if nc else None
+    src_mask = torch.ones(n, 1, Le, dtype=torch.bool, device=dev)
+    ys0 = torch.full((n, 1), synthetic.SOS_ID, dtype=torch.long, device=dev)
+    kd = KVDecoder(model, synthetic.PAD_ID, synthetic.SOS_ID, eos_id=-1)
+    kd.start(z, src_mask, dconds, max_total_len=96)
+    kd.generate(ys0, 80, use_graphs=True, check_every=0)          # warm-up + graph capture
+    fence()
+    t0 = time.perf_counter()
+    kd.start(z, src_mask, dconds, max_total_len=96)               # prefill (cross K/V of all layers) is inside
+    ys = kd.generate(ys0, 80, use_graphs=True, check_every=0)
+    fence()
+    dt = reduce_max(time.perf_counter() - t0)
+    model.train(was_training)
+    return {"metric": "decoded SMILES/sec (KV-cached greedy decode, max_strlen 80)", "value": round(n * world / dt, 1),
+            "unit": "SMILES/s", "n_per_gpu": n, "generated_tokens": int(ys.shape[1]) - 1, "latent_len": Le,
+            "ms_per_token": round(dt / 79 * 1e3, 3), "graph_replay": True, "model_type": a.model_type}
+
+
+# ------------------------------------------------------------------------------------ worker
+def worker(a):
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world == 1:
-        sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (see docstring)")
     if world != a.gpus:
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {a.gpus}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    import torch.distributed as dist
+    cpu = a.selftest_cpu
+    backend = "gloo" if (cpu or a.share_gpu) else a.backend
+    if cpu:
+        dev = torch.device("cpu")
+    else:
+        if a.share_gpu:
+            local = 0
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    from gct_plus_amd import ops, synthetic
-    from gct_plus_amd.Model import forward_propagation, model_dict
-    from gct_plus_amd.Train.trainer1 import loss_function, warmup_lr
-    from gct_plus_amd.dp import FlatDataParallel
-    from gct_plus_amd.optim import FusedAdam
-
-    main_mode = ops.gemm_get_mode()
+    from gct_plus_amd import synthetic
     mtype = a.model_type
-    vs, vt = synthetic.vocab_sizes(mtype)
-    nc = synthetic.n_conds(mtype)
-    torch.manual_seed(1)
-    model = model_dict[mtype](vs, vt, N=6, d_model=512, dff=2048, h=8, latent_dim=128,
-                              dropout=a.dropout, nconds=nc, use_cond2dec=False, use_cond2lat=True)
-    model = model.cuda().train()
-    inner = model
-    if world > 1:
-        model = FlatDataParallel(model)
-    opt = FusedAdam(inner.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-9, model=inner)
+    inner, opt, fwd_loss = (selftest_workload if cpu else hip_workload)(a, dev, world, rank)
+    if not cpu:
+        from gct_plus_amd import ops
+        from gct_plus_amd.Train.trainer1 import warmup_lr
+        main_mode = ops.gemm_get_mode()
+    else:
+        ops, main_mode = None, None
+        warmup_lr = lambda i, d, w: 1e-3                                          # noqa: E731
 
     # synthetic MOSES-shaped pool, sharded like DistributedSampler, staged in HBM up front
-    n_pool = 4
-    ds = synthetic.make_dataset(a.batch * n_pool * world, 80, mtype, seed=0)
-    idx = synthetic.shard_indices(ds["src"].size(0), world, rank, epoch=0, seed=0, shuffle=False)
-    shard = {k: v[idx] for k, v in ds.items()}
-    pool = [{k: v.to(dev) for k, v in b.items()} for b in synthetic.batches(shard, a.batch)]
-    # every rank's first pool batch must pad to S=80 (sample 0 only lives on rank 0)
-    pad_id, beta = synthetic.PAD_ID, 0.04
-    losses = torch.zeros(3, device=dev)
+    S = 20 if (a.tiny or cpu) else 80
+
+    def make_pool(fixed_len):
+        n_pool = 4
+        ds = synthetic.make_dataset(a.batch * n_pool * world, S, mtype, seed=0, fixed_len=fixed_len)
+        idx = synthetic.shard_indices(ds["src"].size(0), world, rank, epoch=0, seed=0, shuffle=False)
+        shard = {k: v[idx] for k, v in ds.items()}
+        return [{k: v.to(dev) for k, v in b.items()} for b in synthetic.batches(shard, a.batch)]
+
+    pool = make_pool(a.fixed_len)
+    state = {"pool": pool}
 
     def step(i):
-        batch = pool[i % len(pool)]
-        prop, mol, mu, lv, _ = forward_propagation[mtype](model, batch, pad_id, False)
-        ys = batch["trg"][:, 1:].contiguous().view(-1)
-        ys_cond = batch["dconds"].unsqueeze(2).contiguous().view(-1, nc, 1) if nc else None
+        batch = state["pool"][i % len(state["pool"])]
+        loss = fwd_loss(batch)
         opt.zero_grad(set_to_none=True)
-        loss, rce, _, kld = loss_function(beta, prop, mol, ys_cond, ys, mu, lv, False, pad_id)
         loss.backward()
         opt.step()
         lr = warmup_lr(i + 1, 512, 8000)
@@ -128,123 +315,189 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not cpu:
+            torch.cuda.synchronize()
+
+    def reduce_max(dt):
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    def region(first, k):
+        """EXACTLY k steps bracketed by barrier + device synchronise on both sides; max over ranks."""
+        fence()
+        t0 = time.perf_counter()
+        last = None
+        for i in range(first, first + k):
+            last = step(i)
+        fence()
+        return reduce_max(time.perf_counter() - t0), last
 
     for i in range(a.warmup):
         step(i)
     fence()
-    if not a.no_kernel_timing:
+    if not cpu and not a.no_kernel_timing:
         ops.PROFILE = {}
         # only the roofline kernel is bracketed by events inside the timed region (all three GEMM
         # kinds cost ~2 % of the step in event overhead); --all-kernel-timing restores the rest
         ops.PROFILE_KINDS = None if a.all_kernel_timing else {"gemm_fwd"}
-    t0 = time.perf_counter()
-    for i in range(a.warmup, a.warmup + a.steps):
-        last = step(i)
-    fence()
-    dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, last = region(a.warmup, a.steps)
+    prof = None
+    if not cpu:
+        prof, ops.PROFILE = ops.PROFILE, None
     final_loss = float(last.item()) / a.batch
+    nxt = a.warmup + a.steps
+
+    # the same step on batches WITHOUT padding (every sample 80 tokens): none of the data-dependent
+    # shortcuts (zero-gradient query tiles, zero rows of the decoder backward) can apply
+    fixed = None
+    if not cpu and not a.no_fixed_len_leg and not a.fixed_len:
+        state["pool"] = make_pool(True)
+        k2 = max(3, a.steps // 3)
+        for i in range(2):
+            step(nxt + i)
+        dt2, _ = region(nxt + 2, k2)
+        nxt += 2 + k2
+        state["pool"] = pool
+        fixed = {"steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 3), "value": round(a.batch * world * k2 / dt2, 1),
+                 "note": "every sample 80 tokens (no padding): worst case of SURVEY.md 8(d)"}
 
     # the same step with the GEMMs on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32), for reference: a short
-    # second timed region after the headline one (every rank runs it, so the collectives stay matched)
+    # further timed region (every rank runs it, so the collectives stay matched)
     alt = None
-    if main_mode == ops.GEMM_BF16X6 and not a.no_alt_mode:
+    if not cpu and main_mode == ops.GEMM_BF16X6 and not a.no_alt_mode:
         ops.gemm_set_mode(ops.GEMM_F32)
         k2 = max(3, a.steps // 3)
         for i in range(2):
-            step(a.warmup + a.steps + i)
-        fence()
-        t1 = time.perf_counter()
-        for i in range(k2):
-            step(a.warmup + a.steps + 2 + i)
-        fence()
-        dt2 = time.perf_counter() - t1
-        if world > 1:
-            tt = torch.tensor([dt2], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt2 = float(tt.item())
+            step(nxt + i)
+        dt2, _ = region(nxt + 2, k2)
+        nxt += 2 + k2
         ops.gemm_set_mode(main_mode)
         alt = {"gemm_arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "steps": k2,
                "ms_per_step": round(dt2 / k2 * 1e3, 3), "value": round(a.batch * world * k2 / dt2, 1)}
 
+    dec = None
+    if not cpu and not a.no_decode and not a.tiny:
+        dec = decode_block(inner, a, dev, world, fence, reduce_max)
+
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = a.batch * world * a.steps / dt
-        roof = None
-        kern = {}
-        if prof:
-            klaunch = {k.split(":", 1)[1]: v for k, v in prof.items() if k.startswith("_x6_kernel_launches:")}
-            for kind, recs in prof.items():
-                if kind.startswith("_"):
-                    continue
-                tsum = sum(e0.elapsed_time(e1) for _, e0, e1 in recs) * 1e-3
-                fsum = sum(f for f, _, _ in recs)
-                kern[kind] = {"launches": len(recs), "avg_us": round(tsum / len(recs) * 1e6, 1),
-                              "tflops": round(fsum / tsum / 1e12, 2),
-                              "share_of_step": round(tsum / dt, 3)}
-                if klaunch.get(kind):        # GEMM calls vs gemm_x6_kernel launches (tail-balanced calls make two)
-                    kern[kind]["kernel_launches"] = klaunch[kind]
-                    kern[kind]["avg_kernel_us"] = round(tsum / klaunch[kind] * 1e6, 1)
-            x6 = "gemm_fwd[x6]" in kern
-            dom = "gemm_fwd[x6]" if x6 else "gemm_fwd"
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_gemm_x6_traffic.json" if x6 else "r01_gemm_fwd_traffic.json")
-            if os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            if x6:
-                # bf16 MFMA pipe, six bf16 partial products per fp32 product: the fp32-equivalent
-                # ceiling of the kernel is the dense bf16 peak / 6
-                peak = PEAK_BF16_MFMA_TFLOPS / 6.0
-                roof = {"kernel": "gemm_x6_kernel<FWD> (nn.Linear forward, exact 3-way bf16 split of both fp32 "
-                                  "operands, 6 partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulate)",
-                        "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": round(peak, 1),
-                        "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / peak, 4),
-                        "traffic": traffic, "avg_launch_us": kern[dom].get("avg_kernel_us", kern[dom]["avg_us"]),
-                        "launches": kern[dom].get("kernel_launches", kern[dom]["launches"]),
-                        "gemm_calls": kern[dom]["launches"], "avg_call_us": kern[dom]["avg_us"],
-                        "note": "avg_launch_us = time of all forward GEMM calls / gemm_x6_kernel<FWD> launches (a "
-                                "tail-balanced call launches the kernel twice plus a small fix-up kernel, which is "
-                                "inside the bracket); achieved/peak in fp32-equivalent (algorithmic) FLOP/s; on the pipe itself: "
-                                f"{round(6 * kern[dom]['tflops'], 1)} of {PEAK_BF16_MFMA_TFLOPS} bf16 TFLOP/s; "
-                                f"the fp32 MFMA pipe these GEMMs ran on before peaks at {PEAK_F32_MFMA_TFLOPS}",
-                        "kernels": kern}
-            else:
-                roof = {"kernel": "gemm_f32_fast_kernel<true,true> (nn.Linear forward, every shape of the step)",
-                        "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
-                        "traffic": traffic, "avg_launch_us": kern[dom]["avg_us"],
-                        "launches": kern[dom]["launches"], "kernels": kern}
-        out = {
-            "metric": "SMILES/sec training step (vaetf, seq_len=80, d_model=512)",
-            "value": round(value, 1), "unit": "SMILES/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "gemm_arithmetic": ("bf16x6: fp32 operands split exactly into 3 bf16 pieces, 6 partial products, fp32 "
-                                "accumulate (error vs fp64 <= the fp32 fma chain's; GCT_GEMM_MODE=f32 selects "
-                                "v_mfma_f32_32x32x2_f32)") if ops.gemm_get_mode() == ops.GEMM_BF16X6
-                               else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
-            "config": {"workload": f"{mtype} training step: 6+6 layers d_model=512 h=8 d_ff=2048 "
-                                   f"latent=128, batch {a.batch}/GPU, seq_len=80 (T=81), dropout "
-                                   f"{a.dropout}, CE+KL loss, fused Adam, fp32 (BASELINE configs[1])",
-                       "global_batch": a.batch * world, "seq_len": 80,
-                       "parallelism": f"dp{world}"},
-            "step_tflops_algorithmic": round(FLOP_PER_SMILES_STEP * value / 1e12, 2),
-            "final_loss_per_sample": round(final_loss, 4),
-            "roofline": roof,
-        }
-        if alt is not None:
-            out["same_step_fp32_mfma_gemms"] = alt
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        launcher = os.environ.get("GCT_BENCH_LAUNCHER") or ("torch.distributed.run" if world > 1 else "single process")
+        if cpu:
+            out = {"metric": "bench.py launcher / step-loop self-test (CPU stand-in model, NOT a benchmark)",
+                   "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+                   "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+                   "vs_baseline": None, "dtype": "f32", "data": "synthetic (self-test)",
+                   "config": {"workload": f"self-test stand-in, batch {a.batch}/rank", "global_batch": a.batch * world,
+                              "seq_len": S, "parallelism": f"dp{world}"},
+                   "ranks": world, "backend": backend, "launcher": launcher,
+                   "final_loss_per_sample": round(final_loss, 4)}
+            print(json.dumps(out), flush=True)
+        else:
+            roof = roofline(prof, dt)
+            out = {
+                "metric": f"SMILES/sec training step ({mtype}, seq_len=80, d_model=512)",
+                "value": round(value, 1), "unit": "SMILES/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "gemm_arithmetic": ("bf16x6: fp32 operands split exactly into 3 bf16 pieces, 6 partial products, fp32 "
+                                    "accumulate (error vs fp64 <= the fp32 fma chain's; GCT_GEMM_MODE=f32 selects "
+                                    "v_mfma_f32_32x32x2_f32)") if ops.gemm_get_mode() == ops.GEMM_BF16X6
+                                   else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                "config": {"workload": f"{mtype} training step: 6+6 layers d_model=512 h=8 d_ff=2048 "
+                                       f"latent=128, batch {a.batch}/GPU, seq_len=80 (T=81), dropout "
+                                       f"{a.dropout}, CE+KL loss, fused Adam, fp32 (BASELINE configs["
+                                       f"{3 if mtype == 'scavaetf' and world > 1 else 1}])"
+                                       + (", TINY dims (launcher test)" if a.tiny else "")
+                                       + (", every sample 80 tokens" if a.fixed_len else
+                                          ", MOSES-like lengths N(35,8) padded to 80"),
+                           "global_batch": a.batch * world, "seq_len": 80,
+                           "parallelism": f"dp{world}"},
+                "ranks": world, "backend": "rccl" if backend == "nccl" else "gloo (host-staged, test rig)",
+                "launcher": launcher,
+                "step_tflops_algorithmic": round(FLOP_PER_SMILES_STEP[mtype] * value / 1e12, 2),
+                "final_loss_per_sample": round(final_loss, 4),
+                "roofline": roof,
+            }
+            if fixed is not None:
+                out["fixed_len_80"] = fixed
+            if alt is not None:
+                out["same_step_fp32_mfma_gemms"] = alt
+            if dec is not None:
+                out["decode"] = dec
+            if world == 1 and not a.no_cpu_baseline and not a.tiny:
+                out["cpu_baseline"] = cpu_baseline()
+            print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def roofline(prof, dt):
+    """`roofline` object for the dominant kernel from the live HIP-event brackets of ops._Timed."""
+    if not prof:
+        return None
+    kern = {}
+    klaunch = {k.split(":", 1)[1]: v for k, v in prof.items() if k.startswith("_x6_kernel_launches:")}
+    for kind, recs in prof.items():
+        if kind.startswith("_"):
+            continue
+        tsum = sum(e0.elapsed_time(e1) for _, e0, e1 in recs) * 1e-3
+        fsum = sum(f for f, _, _ in recs)
+        kern[kind] = {"launches": len(recs), "avg_us": round(tsum / len(recs) * 1e6, 1),
+                      "tflops": round(fsum / tsum / 1e12, 2), "share_of_step": round(tsum / dt, 3)}
+        if klaunch.get(kind):        # GEMM calls vs gemm_x6_kernel launches (tail-balanced calls make two)
+            kern[kind]["kernel_launches"] = klaunch[kind]
+            kern[kind]["avg_kernel_us"] = round(tsum / klaunch[kind] * 1e6, 1)
+    x6 = "gemm_fwd[x6]" in kern
+    dom = "gemm_fwd[x6]" if x6 else "gemm_fwd"
+    if dom not in kern:
+        return None
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (they cannot be collected by this run);
+    # the newest committed summary is quoted together with the commit it was measured at
+    traffic, tsrc = None, None
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_x6_traffic.json" if x6 else "r*_gemm_fwd_traffic.json")))
+    if cands:
+        rec = json.load(open(cands[-1]))
+        traffic = rec.get("hbm_bytes_per_launch")
+        tsrc = {"file": os.path.relpath(cands[-1], ROOT), "commit": rec.get("commit", "unrecorded (round 1)")}
+    if x6:
+        # bf16 MFMA pipe, six bf16 partial products per fp32 product: the fp32-equivalent
+        # ceiling of the kernel is the dense bf16 peak / 6
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+        return {"kernel": "gemm_x6_kernel<FWD> (nn.Linear forward, exact 3-way bf16 split of both fp32 "
+                          "operands, 6 partial products on v_mfma_f32_16x16x32_bf16, fp32 accumulate)",
+                "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / peak, 4),
+                "mfma_utilisation": round(6 * kern[dom]["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4),
+                "traffic": traffic, "traffic_source": tsrc,
+                "traffic_source_commit": tsrc["commit"] if tsrc else None,
+                "avg_launch_us": kern[dom].get("avg_kernel_us", kern[dom]["avg_us"]),
+                "launches": kern[dom].get("kernel_launches", kern[dom]["launches"]),
+                "gemm_calls": kern[dom]["launches"], "avg_call_us": kern[dom]["avg_us"],
+                "note": "avg_launch_us = time of all forward GEMM calls / gemm_x6_kernel<FWD> launches (a "
+                        "tail-balanced call launches the kernel twice plus a small fix-up kernel, which is "
+                        "inside the bracket); achieved/peak in fp32-equivalent (algorithmic) FLOP/s, peak = dense "
+                        f"bf16 {PEAK_BF16_MFMA_TFLOPS} / 6 partial products, so frac = MFMA utilisation; on the pipe "
+                        f"itself: {round(6 * kern[dom]['tflops'], 1)} of {PEAK_BF16_MFMA_TFLOPS} bf16 TFLOP/s; "
+                        f"the fp32 MFMA pipe these GEMMs ran on before peaks at {PEAK_F32_MFMA_TFLOPS}",
+                "kernels": kern}
+    return {"kernel": "gemm_f32_fast_kernel<true,true> (nn.Linear forward, every shape of the step)",
+            "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": traffic, "traffic_source": tsrc, "traffic_source_commit": tsrc["commit"] if tsrc else None,
+            "avg_launch_us": kern[dom]["avg_us"], "launches": kern[dom]["launches"], "kernels": kern}
+
+
+def main():
+    argv = sys.argv[1:]
+    a = parse_args(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_workers(a, argv))          # the parent never imports torch.cuda / touches a GPU
+    worker(a)
 
 
 if __name__ == "__main__":

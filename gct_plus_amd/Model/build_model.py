@@ -34,8 +34,25 @@ def extract_params(args, src_vocab_len, trg_vocab_len):
     }
 
 
+def load_checkpoint(path):
+    """torch.load with the weights-only unpickler (nothing in the file is executed).  A checkpoint written by the
+    reference's trainer holds ONE non-tensor global: `param_groups[0]['lr']` is a numpy float64 scalar
+    (Train/trainer1.py:117-127 computes the lr with numpy and writes it into the optimizer), pickled as
+    numpy.core.multiarray.scalar (numpy._core... under numpy 2) + numpy.dtype.  Exactly those names are allow-listed;
+    anything else in a file is still refused."""
+    import numpy as np
+    try:
+        from numpy._core.multiarray import scalar
+    except ImportError:                                  # numpy 1.x
+        from numpy.core.multiarray import scalar
+    allowed = [scalar, (scalar, "numpy.core.multiarray.scalar"), (scalar, "numpy._core.multiarray.scalar"), np.dtype]
+    allowed += [type(np.dtype(t)) for t in (np.float64, np.float32, np.int64, np.int32)]
+    with torch.serialization.safe_globals(allowed):
+        return torch.load(path, map_location=torch.device("cpu"), weights_only=True)
+
+
 def load_state(model, model_path, rank=0):
-    ckpt = torch.load(model_path, map_location=torch.device("cpu"), weights_only=True)
+    ckpt = load_checkpoint(model_path)
     state = ckpt["model_state_dict"] if isinstance(ckpt, dict) and "model_state_dict" in ckpt else ckpt
     if next(iter(state.keys())).split(".")[0] == "module":
         state = OrderedDict((k[7:], v) for k, v in state.items())

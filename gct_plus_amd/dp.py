@@ -23,28 +23,22 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
-class _HostStaged:
-    """test-only route (gloo ranks sharing one GPU): stage the collective through host memory"""
-
-    def __init__(self, t, pg):
-        self.t, self.h = t, t.detach().cpu()
-        self.w = dist.all_reduce(self.h, op=dist.ReduceOp.SUM, group=pg, async_op=True)
-
-    def wait(self):
-        self.w.wait()
-        self.t.copy_(self.h)
-
-
 class FlatDataParallel(nn.Module):
-    def __init__(self, module: nn.Module, process_group=None, overlap: bool = True):
+    """`allreduce(tensor, pg) -> work` / `broadcast(tensor, pg)` replace the collectives (SUM semantics; the
+    wrapper scales by 1/W): rigs without one GPU per rank inject gct_plus_amd.testing.host_staged_*; the
+    product path leaves them None and talks to RCCL directly."""
+
+    def __init__(self, module: nn.Module, process_group=None, overlap: bool = True, allreduce=None,
+                 broadcast=None):
         super().__init__()
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
         self.overlap = overlap
+        self._ar_fn, self._bc_fn = allreduce, broadcast
         self._flat_ok = getattr(module, "_gct_flat", None) is not None
         self._armed = False
-        self._nccl = dist.get_backend(process_group) == "nccl"
+        self._nccl = dist.get_backend(process_group) == "nccl" and allreduce is None
         self._avg_native = self._nccl
         if self._nccl:
             # RCCL normally provides ReduceOp.AVG; probe once, fall back to SUM + scale if not
@@ -58,12 +52,11 @@ class FlatDataParallel(nn.Module):
                 self._avg_native = False
         with torch.no_grad():
             bufs = [module.flat_params()] if self._flat_ok else [p.data for p in module.parameters()]
-            staged = (not self._nccl) and bufs[0].is_cuda
+            if bufs[0].is_cuda and not self._nccl and broadcast is None:
+                raise RuntimeError("FlatDataParallel: device tensors need the nccl (RCCL) backend")
             for b in bufs:
-                if staged:
-                    h = b.cpu()
-                    dist.broadcast(h, src=0, group=process_group)
-                    b.copy_(h)
+                if broadcast is not None:
+                    broadcast(b, process_group)
                 else:
                     dist.broadcast(b, src=0, group=process_group)
         self._buckets = []
@@ -169,7 +162,7 @@ class FlatDataParallel(nn.Module):
                     p.grad.mul_(1.0 / self.world)
 
     def _allreduce(self, t):
-        if t.is_cuda and not self._nccl:
-            return _HostStaged(t, self.pg)
+        if self._ar_fn is not None:
+            return self._ar_fn(t, self.pg)
         op = dist.ReduceOp.AVG if self._avg_native else dist.ReduceOp.SUM
         return dist.all_reduce(t, op=op, group=self.pg, async_op=True)

@@ -165,7 +165,8 @@ def main(rank, world_size, argv=None):
     optimizer = FusedAdam(inner.parameters(), lr=args.lr, betas=(args.lr_beta1, args.lr_beta2),
                           eps=args.lr_eps, model=inner)
     if args.start_epoch > 1:
-        ck = torch.load(args.model_path, map_location="cpu", weights_only=True)
+        from .Model.build_model import load_checkpoint
+        ck = load_checkpoint(args.model_path)
         optimizer.load_state_dict(ck["opt_state_dict"])
     train_model(args, model, optimizer, train_loader, valid_loader, rank, world_size, LOG)
     if dist.is_initialized():

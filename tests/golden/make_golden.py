@@ -20,6 +20,11 @@ Fixtures:
   g3_history.json         tiny-config 5-step Train.trainer1.run_epoch histories
   g5_decode.pt            tiny-config greedy decode token ids (loop restated around
                           the reference's model.decode)
+  g6_ckpt_<type>[_module].pt  checkpoints WRITTEN BY the reference's own save_checkpoint
+                          (Train/trainer1.py:33-46) after 3 run_epoch steps with stock torch.optim.Adam:
+                          bare keys and DDP-style 'module.'-prefixed keys
+  g6_expect.json          the reference's next 2 steps continued from that state (history), and its
+                          model.encode outputs (mu, log_var, z under pinned eps) for the saved weights
   g4_curve_vaetf.json     (--full) config-1 100-step loss curve, dropout 0
   g4_init_sha.json        (--full) sha256 of each full-size initial tensor (seed 1)
 """
@@ -228,6 +233,71 @@ def g5():
     torch.save(res, os.path.join(HERE, "g5_decode.pt"))
 
 
+class _DdpLike(torch.nn.Module):
+    """state_dict() keys get the 'module.' prefix exactly as under DistributedDataParallel (the reference saves
+    from the wrapper: train1.py:111-112, Train/trainer1.py:42); DDP itself needs a process group."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+
+def g6():
+    """Checkpoint interop: files produced by the reference's save_checkpoint."""
+    expect = {}
+    for mtype in ("pvaetf", "vaetf"):
+        model = build_ref(mtype, dropout=0.0)
+        model.train()
+        nc = synthetic.n_conds(mtype)
+        ds = synthetic.make_dataset(20, max_len=20, model_type=mtype, seed=11)
+        loader = list(synthetic.batches(ds, 4))
+        args = SimpleNamespace(model_type=mtype, pad_id=PAD, use_cond2dec=False,
+                               property_list=["logP", "tPSA", "QED"][:nc],
+                               lr_scheduler="WarmUpDefault", lr_WarmUpSteps=8000, d_model=TINY["d_model"],
+                               N=TINY["N"], d_ff=TINY["dff"], H=TINY["h"], latent_dim=TINY["latent_dim"],
+                               dropout=0.0, use_cond2lat=True, variational=True)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-9)
+        log = logging.getLogger("golden")
+        log.setLevel(logging.ERROR)
+        devnull = open(os.devnull, "w")
+        so = sys.stdout
+        torch.manual_seed(2024)
+        sys.stdout = devnull
+        try:
+            h0, step = ref_tr.run_epoch(args, model, opt, loader[:3], 0, 0.04, log, train=True)
+        finally:
+            sys.stdout = so
+        ref_tr.save_checkpoint(args, model, opt, os.path.join(HERE, f"g6_ckpt_{mtype}.pt"))
+        if mtype == "pvaetf":
+            ref_tr.save_checkpoint(args, _DdpLike(model), opt, os.path.join(HERE, f"g6_ckpt_{mtype}_module.pt"))
+        # encode path on the saved weights (Inference/sampling_tool.py:225-236 calls model.encode), eval mode
+        model.eval()
+        b = loader[0]
+        eps = torch.randn(4, 20 + nc, TINY["latent_dim"], generator=torch.Generator().manual_seed(321))
+        real = torch.randn_like
+        torch.randn_like = lambda t, **kw: eps.clone()
+        try:
+            with torch.no_grad():
+                src_mask = ref_mod.get_src_mask(b["src"], PAD, b.get("econds"))
+                enc = model.encode(b["src"], src_mask, b["econds"]) if nc else model.encode(b["src"], src_mask)
+        finally:
+            torch.randn_like = real
+        z, mu, lv = enc[0], enc[1], enc[2]
+        model.train()
+        torch.manual_seed(77)
+        sys.stdout = devnull
+        try:
+            h1, step = ref_tr.run_epoch(args, model, opt, loader[3:5], step, 0.04, log, train=True)
+        finally:
+            sys.stdout = so
+        expect[mtype] = {"first": {k: [float(x) for x in v] for k, v in h0.items()},
+                         "continued": {k: [float(x) for x in v] for k, v in h1.items()},
+                         "final_step": step, "encode_eps_seed": 321,
+                         "encode": {"z": z.tolist(), "mu": mu.tolist(), "log_var": lv.tolist()},
+                         "final_param_sha256_first": sha(next(model.parameters()))}
+    json.dump(expect, open(os.path.join(HERE, "g6_expect.json"), "w"))
+
+
 def g4(steps=100):
     """Config 1 (vaetf, 6+6, d512, B=64, S=80) loss curve at dropout 0, seed 1."""
     mtype = "vaetf"
@@ -271,8 +341,13 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the 100-step full-size curve")
     ap.add_argument("--only-full", action="store_true")
+    ap.add_argument("--only-g6", action="store_true")
     a = ap.parse_args()
     torch.set_num_threads(8)
+    if a.only_g6:
+        g6()
+        print("g6 fixtures written")
+        sys.exit(0)
     if not a.only_full:
         g1()
         for t in REF_CLASS:
@@ -280,6 +355,7 @@ if __name__ == "__main__":
         g2_cond2dec()
         g3()
         g5()
+        g6()
         print("tiny fixtures written")
     if a.full or a.only_full:
         g4()

@@ -1,0 +1,65 @@
+"""bench.py started plainly with --gpus N > 1 is its own launcher (reference layout:
+train1.py:152-171 spawns one worker per GPU).  On CPU: two gloo ranks drive bench.py's OWN launcher,
+rendezvous, DistributedSampler-equal sharding, FlatDataParallel wrap, step loop, fences, max-over-ranks
+timing and JSON line with the plain-torch stand-in model (--selftest-cpu; the HIP model cannot run without
+a GPU and there is no CPU fallback).  On the GPU box: the same launcher with the real HIP model, two ranks
+sharing the one card (gloo, host-staged collectives)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line on stdout, got {len(lines)}:\n{r.stdout[-2000:]}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mtype", ["vaetf", "scavaetf"])
+def test_plain_gpus2_spawns_two_ranks_cpu(mtype):
+    out = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "8", "--model-type", mtype,
+                "--selftest-cpu"])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["launcher"] == "self-spawn"
+    assert out["backend"] == "gloo" and out["steps"] == 4 and out["warmup"] == 1
+    assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
+    assert out["scaling"] == "weak" and out["ms_per_step"] > 0
+    assert abs(out["value"] - 16 * 4 / (out["ms_per_step"] * 4e-3)) / out["value"] < 1e-2
+    assert "self-test" in out["metric"]              # can never be mistaken for a benchmark line
+
+
+def test_single_rank_cpu_selftest_and_world_mismatch():
+    out = _run(["--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "8", "--selftest-cpu"])
+    assert out["n_gpus"] == 1 and out["launcher"] == "single process"
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-cpu"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "does not match" in r.stderr
+
+
+def test_dead_rank_fails_the_launch():
+    """a worker that dies must take the launch down (non-zero exit), not leave the others in a collective"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["GCT_BENCH_SELFTEST_DIE"] = "1"
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+                        "--selftest-cpu"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_plain_gpus2_real_model_shared_gpu():
+    out = _run(["--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "8", "--model-type", "scavaetf",
+                "--tiny", "--share-gpu", "--no-alt-mode"], timeout=900)
+    assert out["ranks"] == 2 and out["launcher"] == "self-spawn" and out["n_gpus"] == 2
+    assert out["metric"].startswith("SMILES/sec training step (scavaetf")
+    assert out["roofline"] is None or "kernel" in out["roofline"]
+    assert out["fixed_len_80"]["ms_per_step"] > 0
+    assert out["final_loss_per_sample"] == out["final_loss_per_sample"]      # not NaN

@@ -53,8 +53,9 @@ def _worker(rank, world, port, out):
     from gct_plus_amd import synthetic
     from gct_plus_amd.dp import FlatDataParallel
     from gct_plus_amd.optim import FusedAdam
+    from gct_plus_amd.testing import host_staged_allreduce, host_staged_broadcast
     model = _build(100 + rank)                    # different init per rank -> broadcast fixes it
-    ddp = FlatDataParallel(model)
+    ddp = FlatDataParallel(model, allreduce=host_staged_allreduce, broadcast=host_staged_broadcast)
     opt = FusedAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9, model=model)
     ds = synthetic.make_dataset(8 * world * 3, 20, "pvaetf", seed=5)
     g = torch.Generator().manual_seed(9)

@@ -332,6 +332,46 @@ def test_checkpoint_layout_roundtrip(tmp_path, golden_dir):
         assert torch.equal(a.cpu(), b.cpu()), k
 
 
+@pytest.mark.parametrize("name,mtype", [("g6_ckpt_pvaetf.pt", "pvaetf"), ("g6_ckpt_pvaetf_module.pt", "pvaetf"),
+                                        ("g6_ckpt_vaetf.pt", "vaetf")])
+def test_reference_written_checkpoint_continues_on_hip(golden_dir, name, mtype):
+    """G6: a checkpoint written by the REFERENCE's own save_checkpoint (model + stock
+    torch.optim.Adam state after 3 of its run_epoch steps; bare and 'module.'-prefixed keys; vaetf: no Adam state
+    for the 4 dead encoder.fc_* tensors) is loaded through load_state / FusedAdam.load_state_dict; model.encode and
+    the next two training steps reproduce what the reference itself produced from that state."""
+    from gct_plus_amd.Model import get_src_mask, load_checkpoint, load_state
+    from gct_plus_amd.Train.trainer1 import run_epoch
+    from gct_plus_amd.optim import FusedAdam
+    path = os.path.join(golden_dir, name)
+    exp = json.load(open(os.path.join(golden_dir, "g6_expect.json")))[mtype]
+    nc = synthetic.n_conds(mtype)
+    model = load_state(build(mtype, seed=9), path)
+    opt = FusedAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-9, model=model)
+    opt.load_state_dict(load_checkpoint(path)["opt_state_dict"])
+    ds = synthetic.make_dataset(20, max_len=20, model_type=mtype, seed=11)
+    loader = [to_dev(b) for b in synthetic.batches(ds, 4)]
+    # encode path (Inference/sampling_tool.py:225-236): mu, log_var, z against the reference's values
+    model.eval()
+    b = loader[0]
+    set_eps(model, torch.randn(4, 20 + nc, 16, generator=torch.Generator().manual_seed(exp["encode_eps_seed"])))
+    with torch.no_grad():
+        sm = get_src_mask(b["src"], PAD, b.get("econds"))
+        z, mu, lv = model.encode(b["src"], sm, b["econds"]) if nc else model.encode(b["src"], sm)
+    for got, key in ((z, "z"), (mu, "mu"), (lv, "log_var")):
+        assert_close(got, torch.tensor(exp["encode"][key]), 1e-4, 1e-4, f"encode {key}")
+    set_eps(model, None)
+    model.train()
+    (model.sampler if hasattr(model, "sampler") else model.encoder).eps_mode = "cpu"
+    torch.manual_seed(77)
+    hist, step = run_epoch(_args(mtype, 64), model, opt, _Loader(loader[3:5]), 3, 0.04, logging.getLogger("t"), True)
+    assert step == exp["final_step"] == 5
+    for k in ("RCE", "KLD", "LOSS"):
+        for a, e in zip(hist[k], exp["continued"][k]):
+            assert abs(a - e) <= 1e-4 * abs(e), (k, hist[k], exp["continued"][k])
+    for a, e in zip(hist["LR"], exp["continued"]["LR"]):
+        assert abs(a - e) <= 1e-12
+
+
 def test_greedy_decode_token_ids_bit_exact(golden_dir):
     """G5: argmax-decoded ids from model.decode equal the reference's."""
     from gct_plus_amd.Model import get_trg_mask

@@ -159,3 +159,79 @@ def test_cond2dec_path(golden_dir):
     loss.backward()
     for name, e in fx["grads"].items():
         assert torch.allclose(P[name].grad, e, atol=1e-5 * float(e.abs().max()) + 1e-7, rtol=1e-4), name
+
+
+# ------------------------------------------------------------------ G6: reference-written checkpoints
+def _load_ref_ckpt(golden_dir, name):
+    from gct_plus_amd.Model import load_checkpoint          # weights-only loader (+ numpy-scalar allow-list)
+    return load_checkpoint(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize("mtype", ["pvaetf", "vaetf"])
+def test_reference_checkpoint_continues_in_oracle(golden_dir, mtype):
+    """G6: a file written by the REFERENCE's save_checkpoint (3 steps of its run_epoch + stock Adam) is loaded into
+    the oracle (weights + Adam state); the next two steps and model.encode reproduce the reference's."""
+    ck = _load_ref_ckpt(golden_dir, f"g6_ckpt_{mtype}.pt")
+    exp = json.load(open(os.path.join(golden_dir, "g6_expect.json")))[mtype]
+    assert set(ck) == {"model_state_dict", "opt_state_dict", "model_params"}
+    vs, vt = synthetic.vocab_sizes(mtype)
+    nc = synthetic.n_conds(mtype)
+    assert ck["model_params"]["nconds"] == nc and ck["model_params"]["d_ff"] == 128
+    cfg = O.make_cfg(mtype, vs, vt, N=2, d_model=64, dff=128, h=4, latent_dim=16, dropout=0.0, nconds=nc,
+                     use_cond2lat=True)
+    st = O.init_state(cfg, seed=5)
+    assert list(st.keys()) == list(ck["model_state_dict"].keys())      # checkpoint layout == reference's
+    P = O.make_leaves(ck["model_state_dict"])
+    opt = O.make_adam(O.trainable(P, cfg))
+    opt.load_state_dict(ck["opt_state_dict"])
+    ds = synthetic.make_dataset(20, max_len=20, model_type=mtype, seed=11)
+    loader = list(synthetic.batches(ds, 4))
+    # encode path (eval): mu, log_var, z under the pinned eps
+    b = loader[0]
+    eps = torch.randn(4, 20 + nc, 16, generator=torch.Generator().manual_seed(exp["encode_eps_seed"]))
+    with torch.no_grad():
+        sm = O.get_src_mask(b["src"], synthetic.PAD_ID, b.get("econds"))
+        z, mu, lv = O.encode(P, cfg, b["src"], sm, b.get("econds"), eps=eps, train=False)
+    for got, key in ((z, "z"), (mu, "mu"), (lv, "log_var")):
+        assert torch.allclose(got, torch.tensor(exp["encode"][key]), atol=2e-6), key
+    torch.manual_seed(77)
+    for j, batch in enumerate(loader[3:5]):
+        n = batch["src"].size(0)
+        loss, rce, kld, lr = O.train_step(P, cfg, opt, batch, 0.04, synthetic.PAD_ID, 3 + j + 1)
+        for got, key in ((loss, "LOSS"), (rce, "RCE"), (kld, "KLD")):
+            assert abs(got / n - exp["continued"][key][j]) <= 2e-5 * abs(exp["continued"][key][j]), (key, j)
+        assert abs(lr - exp["continued"]["LR"][j]) <= 1e-12
+
+
+def test_reference_checkpoint_module_prefix_and_refusal(golden_dir, tmp_path):
+    a = _load_ref_ckpt(golden_dir, "g6_ckpt_pvaetf.pt")
+    b = _load_ref_ckpt(golden_dir, "g6_ckpt_pvaetf_module.pt")
+    assert ["module." + k for k in a["model_state_dict"]] == list(b["model_state_dict"])
+    assert all(torch.equal(a["model_state_dict"][k], b["model_state_dict"]["module." + k]) for k in a["model_state_dict"])
+    # the reference writes its lr as a numpy scalar: that (and nothing else) is allow-listed
+    assert type(a["opt_state_dict"]["param_groups"][0]["lr"]).__module__ == "numpy"
+    import pickle
+    import subprocess  # noqa: F401  (the refused global below)
+    bad = str(tmp_path / "bad.pt")
+    torch.save({"model_state_dict": {}, "x": subprocess.Popen.__init__}, bad)
+    with pytest.raises(pickle.UnpicklingError):
+        _load_ref_ckpt(str(tmp_path), "bad.pt")
+
+
+def test_full_size_init_hashes(golden_dir):
+    """G4 init: every tensor of the full-size vaetf (config 1, seed 1) built by the oracle AND by the product's
+    module classes hashes to the reference's sha256 (tests/golden/g4_init_sha.json)."""
+    from gct_plus_amd.Model import model_dict
+    ref = json.load(open(os.path.join(golden_dir, "g4_init_sha.json")))
+    cfg = O.make_cfg("vaetf", 28, 30, dropout=0.0, nconds=0, use_cond2lat=True)
+    st = O.init_state(cfg, seed=1)
+    assert list(st.keys()) == list(ref.keys())
+    for k, v in st.items():
+        assert sha(v) == ref[k], f"oracle {k}"
+    torch.manual_seed(1)
+    m = model_dict["vaetf"](28, 30, N=6, d_model=512, dff=2048, h=8, latent_dim=128, dropout=0.0, nconds=0,
+                            use_cond2dec=False, use_cond2lat=True)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k, v in sd.items():
+        assert sha(v) == ref[k], f"product {k}"
