@@ -44,6 +44,7 @@ SIGNATURES = {
     "gct_linear_wgrad": (I32, [P, P, P, I64, I64, I32, I32, P, I64, I32, P, P, P, I64, P, P, P,
                                P, P]),
     "gct_nonzero_row_tiles": (I32, [P, I64, I64, I32, P, P, P, P]),
+    "gct_live_rows": (I32, [P, I64, I32, I32, I32, P, I64, I64, P, P, P, P, P, P, P, P, P]),
     "gct_linear_wgrad_kt": (I32, [P, P, P, I64, I64, I32, I32, P, I64, I32, P, P, P, I64, P, P, P,
                                   P, P, P, P]),
     "gct_dropout_bwd": (I32, [P, P, I64, I32, F32, U64, U32, P]),
@@ -69,7 +70,7 @@ SIGNATURES = {
     "gct_add": (I32, [P, P, P, I64, P]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

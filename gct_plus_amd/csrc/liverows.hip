@@ -1,0 +1,216 @@
+// Live rows of the decoder backward.
+//
+// Under the reference's loss (Train/trainer1.py:21-22: cross-entropy with ignore_index = pad, summed) the
+// gradient entering the decoder is exactly zero on the rows of padded target positions -- 56 % of the rows at
+// MOSES-like lengths.  A row that is zero on entry stays zero through every layer below it ONLY IF no live
+// query row attends to it (then its dK / dV are zero too): every row-wise op (Norm, Linear, GELU, dropout)
+// maps a zero row to a zero row, attention gives zero dQ rows for zero dO rows, but a dead row that is a
+// VISIBLE KEY of a live query receives dK / dV.  With the reference's causal, right-padded trg_mask the
+// property holds; model.forward(trg_mask=...) is a public contract, so it is CHECKED here on the device from
+// the gradient and the mask actually used, and every shortcut built on it (weight-gradient GEMMs over live
+// token tiles, the compacted decoder backward) is taken only when the check passes:
+//
+//   live[b,t]     = row (b,t) of g has a non-zero element
+//   violation     = exists (b,i,j): live[b,i] && !live[b,j] && mask[b,i,j] != 0      (dead key seen by a live query)
+//   non-prefix    = exists (b,t):   !live[b,t] && live[b,t+1]                        (live rows are not 0..n_b-1)
+//
+// gct_live_rows also emits what the shortcuts consume: per-sample counts and offsets, the ascending list of live
+// row ids padded to a multiple of 128 with -1, and the list of 32-row token tiles that hold a live row (ALL tiles
+// when the check fails, so a consumer of the tile list needs no host round trip to stay exact).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void live_flags_kernel(const float* __restrict__ g, int64_t ld, int T, int cols,
+                                                         const uint8_t* __restrict__ mask, int64_t mask_sb,
+                                                         int64_t mask_sq, uint8_t* __restrict__ live,
+                                                         int32_t* __restrict__ n_b, int32_t* __restrict__ info) {
+  extern __shared__ uint8_t lv[];                 // [T]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool vec = (cols % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(g) & 15u) == 0);
+  const int c4 = cols / 4;
+  for (int t = wave; t < T; t += 4) {             // one wave per row
+    const float* row = g + ((int64_t)b * T + t) * ld;
+    int nz = 0;
+    if (vec) {
+      for (int c = lane; c < c4; c += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(row + c * 4);
+        nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+      }
+    } else {
+      for (int c = lane; c < cols; c += 64) nz |= (row[c] != 0.f);
+    }
+    nz = __any(nz);
+    if (lane == 0) lv[t] = (uint8_t)(nz ? 1 : 0);
+  }
+  __syncthreads();
+  int cnt = 0, viol = 0, nonpre = 0;
+  for (int t = tid; t < T; t += 256) {
+    cnt += lv[t];
+    live[(int64_t)b * T + t] = lv[t];
+    if (t + 1 < T && !lv[t] && lv[t + 1]) nonpre = 1;
+  }
+  if (mask == nullptr) {
+    // everything visible: any dead row next to any live row is a visible dead key
+    int anyl = 0, anyd = 0;
+    for (int t = tid; t < T; t += 256) { anyl |= lv[t]; anyd |= !lv[t]; }
+    anyl = __syncthreads_or(anyl);
+    anyd = __syncthreads_or(anyd);
+    viol = (anyl && anyd) ? 1 : 0;
+  } else {
+    const uint8_t* mb = mask + (int64_t)b * mask_sb;
+    for (int idx = tid; idx < T * T; idx += 256) {
+      const int i = idx / T, j = idx - i * T;
+      if (lv[i] && !lv[j] && mb[(int64_t)i * mask_sq + j]) viol = 1;
+    }
+    viol = __syncthreads_or(viol);
+  }
+  cnt = (int)gct_wave_sum((float)cnt);
+  __shared__ int wc[4];
+  if (lane == 0) wc[wave] = cnt;
+  nonpre = __syncthreads_or(nonpre);
+  if (tid == 0) {
+    const int n = wc[0] + wc[1] + wc[2] + wc[3];
+    n_b[b] = n;
+    atomicAdd(&info[0], n);
+    if (viol) atomicAdd(&info[1], 1);
+    if (nonpre) atomicAdd(&info[2], 1);
+  }
+}
+
+// one workgroup: row_off = exclusive scan of n_b; row_list = live row ids ascending, padded with -1 to a
+// multiple of 128; info[4] = padded length
+__global__ __launch_bounds__(1024) void live_lists_kernel(const uint8_t* __restrict__ live, const int32_t* __restrict__ n_b,
+                                                          int B, int T, int32_t* __restrict__ row_off,
+                                                          int32_t* __restrict__ row_list, int32_t* __restrict__ info) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < B; b0 += 1024) {
+    const int b = b0 + tid;
+    const int n = b < B ? n_b[b] : 0;
+    int incl = n;                                   // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    off += incl - n;
+    if (b < B) {
+      if (row_off) row_off[b] = off;
+      if (row_list) {
+        int k = off;
+        const uint8_t* lb = live + (int64_t)b * T;
+        for (int t = 0; t < T; ++t)
+          if (lb[t]) row_list[k++] = b * T + t;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) tot += wsum[w];
+      base += tot;
+    }
+    __syncthreads();
+  }
+  const int total = base, padded = (total + 127) & ~127;
+  if (row_list)
+    for (int k = total + tid; k < padded; k += 1024) row_list[k] = -1;
+  if (tid == 0) {
+    if (row_off) row_off[B] = total;
+    info[4] = padded;
+  }
+}
+
+// flags[t] = 32-row tile t holds a live row, or the dead-key check failed (then every tile is listed)
+__global__ __launch_bounds__(256) void live_tile_flags_kernel(const uint8_t* __restrict__ live, int64_t rows,
+                                                              const int32_t* __restrict__ info,
+                                                              uint8_t* __restrict__ flags, int ntiles) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntiles) return;
+  int f = info[1] != 0;
+  for (int r = 0; r < 32 && !f; ++r) {
+    const int64_t row = (int64_t)t * 32 + r;
+    if (row < rows && live[row]) f = 1;
+  }
+  flags[t] = (uint8_t)f;
+}
+
+__global__ __launch_bounds__(1024) void live_compact_tiles_kernel(const uint8_t* __restrict__ flags, int ntiles,
+                                                                  int32_t* __restrict__ list, int32_t* __restrict__ count,
+                                                                  int32_t* __restrict__ info) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t0 = 0; t0 < ntiles; t0 += 1024) {
+    const int t = t0 + threadIdx.x;
+    const int f = (t < ntiles && flags[t]) ? 1 : 0;
+    const unsigned long long m = __ballot(f);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (f) list[off + before] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) tot += wsum[w];
+      base += tot;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *count = base;
+    info[3] = base;
+  }
+}
+
+}  // namespace
+
+extern "C" int gct_live_rows(const float* g, int64_t ld, int B, int T, int cols, const uint8_t* mask,
+                             int64_t mask_sb, int64_t mask_sq, uint8_t* live, int32_t* n_b, int32_t* info,
+                             int32_t* row_off, int32_t* row_list, int32_t* tile_list, int32_t* tile_count,
+                             uint8_t* tile_flags_ws, void* stream) {
+  GCT_CHECK_ARG(g && live && n_b && info && B >= 0 && T > 0 && cols > 0 && ld >= cols, "live_rows: bad args");
+  GCT_CHECK_ARG(T <= 4096, "live_rows: T = %d unsupported", T);
+  GCT_CHECK_ARG((tile_list == nullptr) == (tile_count == nullptr) && (tile_list == nullptr || tile_flags_ws),
+                "live_rows: tile_list / tile_count / tile_flags_ws go together");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(info, 0, 8 * sizeof(int32_t), st);
+  if (e != hipSuccess) {
+    gct_set_error("live_rows: memset failed: %s", hipGetErrorString(e));
+    return GCT_ERR_HIP;
+  }
+  if (B > 0) {
+    hipLaunchKernelGGL(live_flags_kernel, dim3((unsigned)B), dim3(256), (size_t)((T + 15) & ~15), st, g, ld, T, cols,
+                       mask, mask_sb, mask_sq, live, n_b, info);
+    GCT_LAUNCH_CHECK("live_flags");
+  }
+  if (row_off || row_list) {
+    hipLaunchKernelGGL(live_lists_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)live, (const int32_t*)n_b, B, T,
+                       row_off, row_list, info);
+    GCT_LAUNCH_CHECK("live_lists");
+  }
+  if (tile_list) {
+    const int64_t rows = (int64_t)B * T;
+    const int ntiles = (int)((rows + 31) / 32);
+    if (ntiles > 0) {
+      hipLaunchKernelGGL(live_tile_flags_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, st,
+                         (const uint8_t*)live, rows, (const int32_t*)info, tile_flags_ws, ntiles);
+      GCT_LAUNCH_CHECK("live_tile_flags");
+    }
+    hipLaunchKernelGGL(live_compact_tiles_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)tile_flags_ws, ntiles,
+                       tile_list, tile_count, info);
+    GCT_LAUNCH_CHECK("live_compact_tiles");
+  }
+  return GCT_OK;
+}

@@ -21,6 +21,7 @@ from typing import List, Optional
 import torch
 
 from . import ops
+from .flat import HANDED_SLOTS
 
 _SEED = {"base": None, "ctr": 0}
 
@@ -55,8 +56,9 @@ class GradSink:
     """Where parameter gradients are written.  Parameters of a flattened model carry
     `_gct_gview` (a view into the model's flat gradient buffer); the kernels write straight
     into it and autograd adopts the view as .grad (zero copies).  If .grad already aliases
-    that view (no zero_grad(set_to_none=True) since the last backward) a temporary is used so
-    accumulation semantics stay correct."""
+    that view (no zero_grad(set_to_none=True) since the last backward), or the slot has already been handed
+    to another Function of the same backward pass (model used twice in one graph: flat.HANDED_SLOTS), a
+    temporary is used so accumulation semantics stay correct."""
 
     def __init__(self):
         self.out = {}
@@ -65,10 +67,12 @@ class GradSink:
         t = self.out.get(p)
         if t is None:
             v = getattr(p, "_gct_gview", None)
-            if v is not None and (p.grad is None or p.grad.data_ptr() != v.data_ptr()):
+            if v is not None and id(p) not in HANDED_SLOTS and \
+                    (p.grad is None or p.grad.data_ptr() != v.data_ptr()):
                 # a FRESH view object: AccumulateGrad only adopts (instead of cloning) a
                 # gradient tensor nobody else holds a reference to
                 t = v.view(v.shape)
+                HANDED_SLOTS.add(id(p))
             else:
                 t = torch.empty_like(p)
             self.out[p] = t
@@ -325,19 +329,21 @@ def decoder_trunk_fwd(dec, run: Run, trg, z, src_mask_u8, trg_mask_u8, dconds, w
         p1s.append(p1)
         p2s.append(p2)
     y, mean, rstd = ops.norm_fwd(x, dec.norm.alpha, dec.norm.bias, dec.norm.eps)
-    saved = (trg, z2, dconds, site_pe, lsv, x, mean, rstd, B, T, Le, Lk, c2d, c2l)
+    saved = (trg, z2, dconds, site_pe, lsv, x, mean, rstd, B, T, Le, Lk, c2d, c2l, trg_mask_u8)
     return y.view(B, T, d), saved, p1s, p2s
 
 
 def decoder_trunk_bwd(dec, run: Run, saved, dy, G: GradSink, need_dz=True):
-    trg, z2, dconds, site_pe, lsv, x_last, mean, rstd, B, T, Le, Lk, c2d, c2l = saved
+    trg, z2, dconds, site_pe, lsv, x_last, mean, rstd, B, T, Le, Lk, c2d, c2l, trg_mask_u8 = saved
     d, nc = dec.d_model, dec.nconds
     g = dy.reshape(B * T, d).clone()
     # A decoder row whose incoming gradient is zero (padded target positions under the ignore_index loss)
-    # keeps a zero gradient through every layer below: norm, linear, GELU and dropout backward map a zero row
-    # to a zero row, attention gives zero dQ rows for zero dO rows and masked keys receive no dK / dV.  The
-    # weight-gradient GEMMs over decoder rows therefore reduce over the non-zero 32-row tiles only (exact).
-    run.kt = ops.nonzero_row_tiles(g) if (B * T) % 32 == 0 else None
+    # keeps a zero gradient through every layer below -- norm, linear, GELU and dropout backward map a zero row
+    # to a zero row, attention gives zero dQ rows for zero dO rows -- PROVIDED no live query attends to it (a dead
+    # row that is a visible key receives dK / dV).  ops.LiveRows derives the live rows from the gradient and checks
+    # that proviso on the device against the trg_mask this call used (csrc/liverows.hip); its tile list names
+    # every tile when the check fails, so the weight-gradient GEMMs below stay exact for any mask / loss.
+    run.kt = ops.LiveRows(g, B, T, trg_mask_u8, lists=False).kt if (B * T) % 32 == 0 else None
     ops.norm_bwd(g, x_last, dec.norm.alpha, mean, rstd, G(dec.norm.alpha), G(dec.norm.bias), out=g,
                  eps=dec.norm.eps)
     de = _empty(B * Lk, d, g)

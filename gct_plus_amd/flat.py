@@ -17,6 +17,18 @@ import torch.nn as nn
 
 ALIGN = 8  # floats: 16-B aligned fp32 slots AND 16-B aligned slots in the bf16 weight planes
 
+# Gradient-slot ownership inside ONE backward pass (engine.GradSink): a parameter's slot of the flat gradient
+# buffer may be handed to the kernels of only one autograd.Function per pass.  If the model (or model.decode /
+# a sub-module) is used twice inside one graph -- (loss1 + loss2).backward() -- the second Function must write
+# to a temporary, otherwise autograd's input buffer would add a tensor to its own alias (2*g2 instead of g1+g2).
+# The id is released by the parameter's post-accumulate hook, and wholesale by sync_grads_to_flat() (optimizer
+# step: no backward pass is in flight), which also recovers from passes that never accumulate (autograd.grad).
+HANDED_SLOTS = set()
+
+
+def _release_slot(p):
+    HANDED_SLOTS.discard(id(p))
+
 
 class FlatModelMixin:
     """Mixed into the top-level model classes.  Flattening happens automatically whenever
@@ -54,6 +66,9 @@ class FlatModelMixin:
                 v.copy_(p.data)
                 p.data = v
                 p._gct_gview = gflat[o:o + p.numel()].view(p.shape)
+                if not getattr(p, "_gct_release_hook", False):
+                    p.register_post_accumulate_grad_hook(_release_slot)
+                    p._gct_release_hook = True
                 if p.grad is not None:
                     p._gct_gview.copy_(p.grad)
                     p.grad = None
@@ -131,6 +146,7 @@ class FlatModelMixin:
         slots of parameters that received no gradient this step (Vaetf's dead encoder.fc_*,
         SURVEY 2.3) and point every .grad at its slot."""
         self._require_flat()
+        HANDED_SLOTS.clear()
         for p in self._gct_flat["order"]:
             if p.grad is None:
                 p._gct_gview.zero_()

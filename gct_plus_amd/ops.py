@@ -307,6 +307,43 @@ def nonzero_row_tiles(x2d: torch.Tensor):
     return lst, cnt
 
 
+class LiveRows:
+    """Device-side description of the rows of a decoder gradient that are not identically zero, plus the check
+    that makes shortcuts on them exact (csrc/liverows.hip).  `kt` feeds linear_wgrad(kt=...): it lists every tile
+    when the check failed, so it needs no host decision.  `host()` reads the five counters back (one sync)."""
+
+    def __init__(self, g2d, B, T, mask_u8, lists=True):
+        _chk(g2d, "g2d")
+        dev = g2d.device
+        M = B * T
+        assert g2d.shape[0] == M
+        nt = (M + 31) // 32
+        i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)            # noqa: E731
+        self.B, self.T, self.M = B, T, M
+        self.live = torch.empty(max(M, 1), dtype=torch.uint8, device=dev)
+        self.n_b, self.info = i32(B), i32(8)
+        self.row_off = i32(B + 1) if lists else None
+        self.row_list = i32(M + 128) if lists else None
+        self.tile_list, self.tile_count = i32(nt), i32(1)
+        flags = torch.empty(max(nt, 1), dtype=torch.uint8, device=dev)
+        if mask_u8 is None:
+            sb = sq = 0
+        else:
+            _chk(mask_u8, "live_rows.mask", torch.uint8)
+            sb, sq = _mask_strides(mask_u8, B, T, T)
+        check(_L().gct_live_rows(_p(g2d), g2d.stride(0), B, T, g2d.shape[1], _p(mask_u8), sb, sq, _p(self.live),
+                                 _p(self.n_b), _p(self.info), _p(self.row_off), _p(self.row_list),
+                                 _p(self.tile_list), _p(self.tile_count), _p(flags), _st()), "gct_live_rows")
+        self.kt = (self.tile_list, self.tile_count)
+        self._host = None
+
+    def host(self):
+        if self._host is None:
+            v = self.info.tolist()
+            self._host = dict(n_live=v[0], violations=v[1], nonprefix=v[2], tiles=v[3], padded=v[4])
+        return self._host
+
+
 def linear_wgrad(dys: Sequence[torch.Tensor], lddy: int, x2d, dws: Sequence[torch.Tensor],
                  dbs: Sequence[Optional[torch.Tensor]], kt=None):
     M, K = x2d.shape

@@ -37,7 +37,7 @@ extern "C" {
 #define GCT_ERR_ARG (-1)  /* bad shape / alignment / null pointer            */
 #define GCT_ERR_HIP (-2)  /* a HIP runtime call failed (launch error)        */
 
-#define GCT_ABI_VERSION 2
+#define GCT_ABI_VERSION 3
 
 int gct_version(void);
 const char* gct_last_error(void);
@@ -129,7 +129,7 @@ int gct_linear_wgrad(const float* dy0, const float* dy1, const float* dy2, int64
  *   GCT_GEMM_F32    : v_mfma_f32_32x32x2_f32 (fp32 fma chains);
  *   GCT_GEMM_BF16X6 : every operand element is split EXACTLY into three bf16 values (8+8+8
  *                     significand bits) and the six leading partial products are accumulated in
- *                     fp32 by v_mfma_f32_32x32x16_bf16; launches that do not qualify (odd shapes,
+ *                     fp32 by v_mfma_f32_16x16x32_bf16; launches that do not qualify (odd shapes,
  *                     skinny M, no planes for fwd/dgrad) use the fp32 kernels.
  * Process-wide; default from the environment (GCT_GEMM_MODE=f32|x6, x6 when unset). */
 #define GCT_GEMM_F32 0
@@ -177,6 +177,22 @@ int64_t gct_linear_dgrad_ws_bytes(int64_t M, int Ntot, int K);
  * honoured by the bf16x6 kernel; the fp32 kernels reduce over all rows (same result). */
 int gct_nonzero_row_tiles(const float* x, int64_t ld, int64_t rows, int cols, int32_t* list,
                           int32_t* count, uint8_t* flags_ws, void* stream);
+/* The property above holds only if no live query row attends to a dead (zero-gradient) row: a dead row that is a
+ * VISIBLE KEY of a live query receives dK / dV.  gct_live_rows derives the live rows of g[B*T][cols] and CHECKS the
+ * property on the device against the self-attention mask actually used (mask element (b,i,j) at
+ * mask[b*mask_sb + i*mask_sq + j]; NULL = everything visible; mask_sq == 0 = key-padding mask):
+ *   live [B*T] u8; n_b [B] live rows per sample;
+ *   info [8] i32: [0] live rows, [1] samples with a dead key visible to a live query (violations),
+ *                 [2] samples whose live rows are not the prefix 0..n_b-1, [3] listed token tiles,
+ *                 [4] length of row_list (live rows rounded up to a multiple of 128);
+ *   row_off  [B+1] (nullable) exclusive prefix sum of n_b;
+ *   row_list [B*T+128] (nullable) ascending live row ids, padded with -1;
+ *   tile_list / tile_count / tile_flags_ws (nullable, together): the 32-row token tiles that hold a live row --
+ *   EVERY tile when info[1] != 0, so gct_linear_wgrad_kt stays exact without a host round trip. */
+int gct_live_rows(const float* g, int64_t ld, int B, int T, int cols, const uint8_t* mask, int64_t mask_sb,
+                  int64_t mask_sq, uint8_t* live, int32_t* n_b, int32_t* info, int32_t* row_off,
+                  int32_t* row_list, int32_t* tile_list, int32_t* tile_count, uint8_t* tile_flags_ws,
+                  void* stream);
 int gct_linear_wgrad_kt(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
                         int64_t M, int nseg, int nper, const float* x, int64_t ldx, int K,
                         float* dw0, float* dw1, float* dw2, int64_t lddw,

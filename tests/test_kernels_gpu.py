@@ -418,6 +418,98 @@ def test_linear_bf16x6_vs_fp64(ops, M, K, nper, nseg):
         assert e6 <= 2.0 * e32 + 1e-9, f"{what}: bf16x6 mean error {e6:.3e} vs fp32-MFMA {e32:.3e}"
 
 
+def _adversarial(kind, M, K, N):
+    """Operand sets that stress the 3-way bf16 split.  Returns x [M,K], w [N,K], dy [M,N]."""
+    x, w, dy = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=K ** -0.5), rnd(M, N, seed=33)
+    if kind == "cancel":
+        # second half of K cancels the first to 12 bits: the result is 2^-12 of the sum of magnitudes
+        x = torch.cat([x, x], 1)
+        w = torch.cat([w, -w * (1 + 2.0 ** -12)], 1)
+    elif kind == "scales":
+        # per-k scale 2^e on x, 2^-e on w (|e| <= 60, ~1e+-18): exact in binary, products unchanged
+        e = torch.randint(-60, 61, (K,), generator=torch.Generator().manual_seed(5)).float()
+        x, w = x * torch.exp2(e), w * torch.exp2(-e)
+        dy = dy * torch.exp2(torch.randint(-60, 61, (N,), generator=torch.Generator().manual_seed(6)).float())
+    elif kind == "ones":
+        # every significand all ones (2 - 2^-23) * 2^e: h rounds UP, m and l are negative, dropped terms are maximal
+        full = 2.0 - 2.0 ** -23
+        mk = lambda t, sd: torch.sign(t) * full * torch.exp2(                                     # noqa: E731
+            torch.randint(-3, 4, t.shape, generator=torch.Generator().manual_seed(sd)).float())
+        x, w, dy = mk(x, 7), mk(w, 8) * K ** -0.5, mk(dy, 9)
+    elif kind == "tiny":
+        # gradients at the bottom of the fp32 normal range (x, w stay O(1)): the low bf16 pieces of dy leave bf16's
+        # normal range and are flushed (documented in gemm_x6.inc: an ABSOLUTE error below 2^-126 per piece)
+        dy = dy * 2.0 ** -112
+    return x.float(), w.float(), dy.float()
+
+
+@pytest.mark.parametrize("kind", ["cancel", "scales", "ones", "tiny"])
+def test_linear_bf16x6_adversarial_vs_fp64(ops, kind):
+    """Worst-case bound stated in gemm_x6.inc: with u = 2^-8 (bf16 unit round-off) the pieces satisfy |m| <= u|x|,
+    |l| <= u^2|x|, so the three dropped partial products are bounded by (2u^3 + u^4)|a b| < 2^-23 |a b| per product
+    (typical 2^-26); accumulation is fp32 like the fp32-MFMA kernel's, whose own worst relative error on the same
+    data (r32 = max |err32| / sum_k |a_k b_k|) stands in for that shared term.  Asserted per output element:
+        |err| <= (2^-23 + 1.5 * r32) * sum_k |a_k b_k|  +  flush floor,
+    and the mean error never worse than 2x the fp32-MFMA kernel's on the same data (+ the same floor)."""
+    M, K0, N = 6144, 512, 512
+    x, w, dy = _adversarial(kind, M, K0, N)
+    K = x.shape[1]
+    b = rnd(N, seed=34) * (0.0 if kind in ("cancel", "tiny") else 1.0)
+    xg, dyg, bg = x.to(DEV), dy.to(DEV), b.to(DEV)
+    flat, (wg,) = _planes_for(ops, [w])
+    res = {}
+    try:
+        for mode in (ops.GEMM_F32, ops.GEMM_BF16X6):
+            ops.gemm_set_mode(mode)
+            c0 = ops.gemm_launch_counts()
+            y, dx = torch.empty(M, N, device=DEV), torch.empty(M, K, device=DEV)
+            dw, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+            ops.linear_fwd(xg, [wg], [bg], [y], N)
+            ops.linear_dgrad([dyg], N, M, [wg], dx)
+            ops.linear_wgrad([dyg], N, xg, [dw], [db])
+            res[mode] = (y.cpu().double(), dx.cpu().double(), dw.cpu().double(), ops.gemm_launch_counts()[1] - c0[1])
+    finally:
+        ops.gemm_set_mode(ops.GEMM_BF16X6)
+        ops.unregister_planes(flat)
+    assert res[ops.GEMM_BF16X6][3] == 3 and res[ops.GEMM_F32][3] == 0          # all three ran on the bf16x6 kernels
+    X, W, DY = x.double(), w.double(), dy.double()
+    refs = (X @ W.t() + b.double(), DY @ W, DY.t() @ X)
+    mags = (X.abs() @ W.abs().t() + b.double().abs(), DY.abs() @ W.abs(), DY.abs().t() @ X.abs())
+    # pieces below bf16's normal range are flushed: < 2^-126 per piece and product partner
+    floors = (3 * 2.0 ** -126 * W.abs().sum(1)[None, :], 3 * 2.0 ** -126 * W.abs().sum(0)[None, :],
+              3 * 2.0 ** -126 * (DY.abs().sum(0)[:, None] + X.abs().sum(0)[None, :]))
+    for i, what in enumerate(("fwd", "dgrad", "wgrad")):
+        e6 = (res[ops.GEMM_BF16X6][i] - refs[i]).abs()
+        e32 = (res[ops.GEMM_F32][i] - refs[i]).abs()
+        assert torch.isfinite(res[ops.GEMM_BF16X6][i]).all(), what
+        r32 = (e32 / mags[i].clamp_min(1e-300)).max().item()
+        bound = (2.0 ** -23 + 1.5 * r32) * mags[i] + floors[i]
+        worst = (e6 / bound).max().item()
+        assert worst <= 1.0, f"{kind} {what}: error {worst:.3f} x the stated bound (r32 = {r32:.3e})"
+        assert e6.mean().item() <= 2.0 * e32.mean().item() + floors[i].mean().item() + 1e-300, \
+            f"{kind} {what}: bf16x6 mean error {e6.mean().item():.3e} vs fp32-MFMA {e32.mean().item():.3e}"
+
+
+def test_linear_bf16x6_nonfinite_inputs_documented(ops):
+    """gemm_x6.inc range notes, pinned: an infinite operand (or |x| > 3.39e38, which rounds to inf in bf16) gives NaN
+    where exact-fp32 arithmetic gives inf (inf - inf in the residual); NaN stays NaN; finite rows are untouched."""
+    M, K, N = 6144, 512, 512
+    x, w = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=K ** -0.5)
+    x[5, 7], x[9, 3], x[11, 1] = float("inf"), 3.4e38, float("nan")
+    flat, (wg,) = _planes_for(ops, [w])
+    try:
+        y = torch.empty(M, N, device=DEV)
+        ops.linear_fwd(x.to(DEV), [wg], [torch.zeros(N, device=DEV)], [y], N)
+    finally:
+        ops.unregister_planes(flat)
+    y = y.cpu()
+    assert not torch.isfinite(y[5]).any() and not torch.isfinite(y[9]).any() and torch.isnan(y[11]).all()
+    keep = torch.ones(M, dtype=torch.bool)
+    keep[[5, 9, 11]] = False
+    assert torch.isfinite(y[keep]).all()
+    close(y[keep], x[keep].double() @ w.double().t(), 2e-5, 2e-5, "finite rows next to non-finite ones")
+
+
 @pytest.mark.parametrize("M,N", [(640, 2048), (128 * 66 + 40, 1024)])
 def test_linear_bf16x6_epilogues_and_dropout_masks(ops, M, N):
     """Fused epilogues in bf16x6 mode: same dropout masks as the fp32 kernels (the mask depends on

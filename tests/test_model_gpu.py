@@ -372,6 +372,130 @@ def test_reference_written_checkpoint_continues_on_hip(golden_dir, name, mtype):
         assert abs(a - e) <= 1e-12
 
 
+def test_two_forwards_one_backward_accumulates(golden_dir):
+    """ADVICE r1 (engine.GradSink): the model used twice inside ONE autograd graph -- (loss_a + loss_b).backward()
+    -- must give g_a + g_b; both Function backwards run before AccumulateGrad, so the second one may not be handed
+    the same flat-gradient slot.  Checked against the two gradients computed in separate passes and the oracle."""
+    from oracle import gct_oracle as O
+    mtype = "pscavaetf"
+    fx = torch.load(os.path.join(golden_dir, f"g2_{mtype}.pt"), weights_only=True)
+    ds = synthetic.make_dataset(4, max_len=20, model_type=mtype, seed=21)
+    model = build(mtype).train()
+    set_eps(model, fx["eps"])
+    sep = {}
+    for batch in (fx["batch"], ds):
+        model.zero_grad(set_to_none=True)
+        run_fwd_loss(model, mtype, batch, 0.04)[5].backward()
+        for n, p in model.named_parameters():
+            sep[n] = sep.get(n, 0) + p.grad.detach().clone()
+    model.zero_grad(set_to_none=True)
+    la = run_fwd_loss(model, mtype, fx["batch"], 0.04)[5]
+    lb = run_fwd_loss(model, mtype, ds, 0.04)[5]
+    (la + lb).backward()
+    floor = grad_floor(list(sep.values()))
+    for n, p in model.named_parameters():
+        assert_close(p.grad, sep[n], 1e-6 * float(sep[n].abs().max()) + floor, 1e-5, f"joint vs separate {n}")
+    # and against the oracle (CPU restatement of the reference) on the joint loss
+    vs, vt = synthetic.vocab_sizes(mtype)
+    cfg = O.make_cfg(mtype, vs, vt, dropout=0.0, nconds=3, use_cond2lat=True, **TINY)
+    P = O.make_leaves(O.init_state(cfg, seed=1))
+    tot = 0
+    for batch in (fx["batch"], ds):
+        sm, tm, trg_in = O.batch_masks(cfg, batch, PAD)
+        _, mol, mu, lv, _ = O.forward(P, cfg, batch["src"], trg_in, sm, tm, batch["econds"], batch["dconds"],
+                                      eps=fx["eps"], train=True)
+        tot = tot + O.loss_function(0.04, None, mol, batch["dconds"].unsqueeze(2), batch["trg"][:, 1:].reshape(-1),
+                                    mu, lv, False, PAD)[0]
+    tot.backward()
+    for n, p in model.named_parameters():
+        e = P[n].grad
+        assert_close(p.grad, e, 1e-5 * float(e.abs().max()) + floor, 1e-3, f"joint vs oracle {n}")
+    # the usual single-use step afterwards still writes straight into the flat buffer
+    model.zero_grad(set_to_none=True)
+    run_fwd_loss(model, mtype, ds, 0.04)[5].backward()
+    assert model.grads_are_flat()
+
+
+@pytest.mark.parametrize("case", ["last_token_loss", "no_trg_mask", "left_padded", "right_padded_reference"])
+def test_zero_gradient_rows_with_arbitrary_masks_vs_oracle(case):
+    """VERDICT r1 2a / ADVICE (engine.py:340): the decoder backward reduces its weight gradients over the token tiles
+    that hold a non-zero incoming gradient.  That is exact only while no live query attends to a dead row; the guard
+    (ops.LiveRows, csrc/liverows.hip) checks it on the device from the gradient and the mask of THIS call.  B*T = 512
+    rows (% 32 == 0) with >= 32 consecutive zero-gradient rows in every case; all gradients against the oracle.
+      last_token_loss : causal mask, loss on the last position only -> live query sees 63 dead keys (guard must trip)
+      no_trg_mask     : trg_mask=None, padded ys                   -> dead rows are visible keys    (guard must trip)
+      left_padded     : tokens right-aligned, pad & causal mask    -> dead rows invisible, NOT a prefix (shortcut ok)
+      right_padded_reference : the reference's own masks            -> shortcut taken"""
+    from gct_plus_amd import ops
+    from gct_plus_amd.Model import get_src_mask, get_trg_mask
+    from gct_plus_amd.Train.trainer1 import loss_function
+    from oracle import gct_oracle as O
+    mtype, B, S = "pvaetf", 8, 63
+    T = S + 1
+    model = build(mtype, seed=3).train()
+    vs, vt = synthetic.vocab_sizes(mtype)
+    cfg = O.make_cfg(mtype, vs, vt, dropout=0.0, nconds=3, use_cond2lat=True, **TINY)
+    P = O.make_leaves({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    g = torch.Generator().manual_seed(17)
+    ds = synthetic.make_dataset(B, max_len=S, model_type=mtype, seed=41)
+    lens = torch.randint(8, 20, (B,), generator=g)                # short samples: > 40 padded positions each
+    src = torch.full((B, S), PAD, dtype=torch.long)
+    trg = torch.full((B, S + 2), PAD, dtype=torch.long)
+    for b in range(B):
+        n = int(lens[b])
+        toks = ds["src"][0, :n]
+        if case == "left_padded":
+            src[b, S - n:] = toks
+            trg[b, S + 2 - (n + 2):] = torch.cat([torch.tensor([synthetic.SOS_ID]), toks + 2,
+                                                  torch.tensor([synthetic.EOS_ID])])
+        else:
+            src[b, :n] = toks
+            trg[b, :n + 2] = torch.cat([torch.tensor([synthetic.SOS_ID]), toks + 2, torch.tensor([synthetic.EOS_ID])])
+    if case == "last_token_loss":
+        src, trg = ds["src"].clone(), ds["trg"].clone()           # full-length rows; only the loss is sparse
+        src[:, :] = ds["src"][0]
+        trg[:, :] = ds["trg"][0]
+    trg_in, ys = trg[:, :-1].contiguous(), trg[:, 1:].contiguous()
+    if case == "last_token_loss":
+        ys = ys.clone()
+        ys[:, :-1] = PAD                                           # ignore_index everywhere but the last position
+    econds = ds["econds"]
+    src_mask = get_src_mask(src, PAD, econds)
+    trg_mask = None if case == "no_trg_mask" else get_trg_mask(trg_in, PAD, False, econds)
+    eps = torch.randn(B, S + 3, TINY["latent_dim"], generator=g)
+    set_eps(model, eps)
+    cu = lambda t: None if t is None else t.cuda()                 # noqa: E731
+    prop, mol, mu, lv, z = model(cu(src), cu(trg_in), cu(src_mask), cu(trg_mask), cu(econds), cu(econds))
+    yc = econds.unsqueeze(2).contiguous().view(-1, 3, 1).cuda()
+    loss = loss_function(0.04, prop, mol, yc, ys.view(-1).cuda(), mu, lv, False, PAD)[0]
+    _, omol, omu, olv, _ = O.forward(P, cfg, src, trg_in, src_mask, trg_mask, econds, econds, eps=eps, train=True)
+    oloss = O.loss_function(0.04, None, omol, econds.unsqueeze(2), ys.view(-1), omu, olv, False, PAD)[0]
+    assert_close(mol, omol, 1e-4, 1e-4, "logits")
+    assert abs(loss.item() - oloss.item()) <= 2e-5 * abs(oloss.item())
+    # what the guard sees for this call's decoder gradient
+    dmol = torch.autograd.grad(loss, mol, retain_graph=True)[0]
+    lr = ops.LiveRows(dmol.reshape(B * T, -1).contiguous(), B, T, ops.to_mask_u8(cu(trg_mask)))
+    h = lr.host()
+    dead_run = 0
+    run_len = 0
+    for f in lr.live[:B * T].tolist():
+        run_len = 0 if f else run_len + 1
+        dead_run = max(dead_run, run_len)
+    assert dead_run >= 32, dead_run
+    assert h["n_live"] == int((ys != PAD).sum())
+    if case in ("last_token_loss", "no_trg_mask"):
+        assert h["violations"] > 0 and h["tiles"] == B * T // 32      # every tile listed: dense reduction
+    else:
+        assert h["violations"] == 0 and h["tiles"] < B * T // 32      # shortcut in force
+        assert (h["nonprefix"] > 0) == (case == "left_padded")
+    loss.backward()
+    oloss.backward()
+    floor = grad_floor(v.grad for v in P.values())
+    for name, p in model.named_parameters():
+        e = P[name].grad
+        assert_close(p.grad, e, 1e-5 * float(e.abs().max()) + floor, 1e-3, f"{case}: grad {name}")
+
+
 def test_greedy_decode_token_ids_bit_exact(golden_dir):
     """G5: argmax-decoded ids from model.decode equal the reference's."""
     from gct_plus_amd.Model import get_trg_mask
