@@ -1,26 +1,36 @@
-// K4: multi-head attention core, forward and backward.
+// K4: multi-head attention core, forward and backward, L <= 208.
 // Reference: Model/sublayers.py:29-41 attention():  softmax(q k^T / sqrt(dk) masked_fill(mask==0,
 // -1e9)) -> dropout on the probabilities -> . v ; head split/merge of sublayers.py:64-69 is
 // folded into the addressing (q/k/v are read in place from the fused projection buffer, o is
-// written heads-merged).
+// written heads-merged).  The reference's positional table allows any L <= 200 (Model/modules.py:117).
 //
-// Machine mapping (gfx950): L <= 128 and dk <= 64, so a whole (batch, head) problem lives in one
-// workgroup's LDS: Q (pre-scaled), K, V [L][dk+4] fp32 plus one flag byte per (q,k) holding
-// {in-range, not-masked, dropout-keep}.  All products run on v_mfma_f32_16x16x4_f32 (exact fp32).
+// Machine mapping (gfx950).  One (batch, head) "pair" at a time lives in a workgroup's LDS: K and V
+// [L][dk+4] fp32.  All products run on v_mfma_f32_16x16x4_f32 (exact fp32).
 //  * The score tile is computed TRANSPOSED (S^T = K Q^T): its accumulator layout has the key
 //    index on the registers and the query on the lane -- exactly the B-operand layout of the
 //    following P.V product (which sums over keys).  Probabilities never leave registers and
 //    never touch HBM; a softmax row is reduced over 4 regs x tiles in-lane plus two shuffles.
-//  * 16x16 score tiles whose mask bytes are all zero (above the causal diagonal, beyond a
-//    sample's length) are skipped -- decided from the staged flags, wave-uniform, and only
-//    when every query row of the tile has at least one visible key, so the masked_fill(-1e9)
-//    semantics (uniform row when everything is masked) stay exact.
-//  * staging loads are issued in batches (fully unrolled, loads before LDS stores) and the
-//    workgroup is 8 (fwd) / 12 (bwd) waves so HBM/L2 latency overlaps the MFMA phases.
-//  * Backward recomputes probabilities from the saved log-sum-exp (no [B,H,L,L] tensor):
-//      pass A (one wave per query tile):  S^T, dP^T -> dS^T -> dQ
-//      pass B (one wave per key tile)  :  S, dP -> P_drop, dS -> dV, dK
-//    both passes only read LDS, so they run CONCURRENTLY on different waves of the workgroup.
+//  * Masks arrive PACKED (gct_attn_mask_pack: one bit per key, 8 words per query row, packed once per
+//    forward and shared by all layers and heads).  A lane holds the words of its own query row in
+//    registers; visibility of a 16x16 tile, "row has a visible key" and the per-element mask bit are
+//    all bit operations on them -- no flag bytes in LDS (the previous kernel staged Lq x Lk of them).
+//  * 16x16 score tiles without a visible (q,k) are skipped -- wave-uniform, and only when every query
+//    row of the tile has at least one visible key, so the masked_fill(-1e9) semantics (uniform row
+//    when everything is masked) stay exact.  Dropout keep bits: one Philox call per (query, 4 keys) in
+//    the lane that owns them, only for tiles that are computed.
+//  * Workgroups are PERSISTENT (grid = 2 per CU, 6 waves each) and software-pipelined over their pairs:
+//    the next pair's K, V (staging registers) and this wave's Q fragment are requested from HBM before
+//    the current pair's MFMAs start and are written to LDS after them, so HBM latency hides behind
+//    compute inside one workgroup instead of relying on co-resident workgroups drifting apart (the
+//    previous kernel's workgroups ran load -> compute in lockstep: 143 us for 336 MB).
+//  * Backward recomputes probabilities from the saved log-sum-exp (no [B,H,L,L] tensor) in two phases
+//    that REUSE one LDS region:
+//      phase A (K, V in LDS; one wave per query tile, Q / dO / O rows straight from HBM):
+//               S^T, dP^T -> dS^T -> dQ;   also delta = rowsum(dO * O), lse and "dO row is non-zero" -> LDS
+//      phase B (Q, dO in LDS -- their second read hits L2; one wave per key tile, K / V rows from L2):
+//               S, dP -> P_drop, dS -> dV, dK
+//    so every tensor crosses HBM once and a pair needs 2 x L x (dk+4) floats of LDS, not 4 x (L <= 256
+//    fits; 2-3 workgroups per CU at L = 80).  Query tiles whose dO rows are all zero are skipped in both.
 // Roofline: HBM-bound on q,k,v,o (+ gradients); 4.L.d flop/token ~ 3 % of the step's flops.
 #include "common.h"
 
@@ -28,14 +38,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int NT_MAX = 8;  // L <= 128
-constexpr int FWD_THREADS = 512, BWD_THREADS = 768;
+constexpr int ATT_THREADS = 384;       // 6 waves: one per query / key tile at L <= 96
+constexpr int MASK_W = 8;              // packed mask: 8 x 32 bits per query row
+constexpr int L_MAX = 208;             // 13 tiles of 16: covers the reference's 200-row positional table + 3 conditions
 
 struct AttnArgs {
   const float *q, *k, *v;
   int64_t ldq, ldk, ldv;
-  const uint8_t* mask;
-  int64_t mask_sb, mask_sq;
+  const uint32_t* mbits;               // packed mask rows (nullable = everything visible)
+  int64_t mb_sb, mb_sq;                // strides in words: per batch, per query row (0: key-padding mask)
   float* o;
   int64_t ldo;
   float* lse;
@@ -44,46 +55,27 @@ struct AttnArgs {
   const float *o_in, *dout, *lse_in;
   float *dq, *dk, *dv;
   int64_t lddq, lddk, lddv;
-  int B, H, Lq, Lk;
+  int B, H, Lq, Lk, npairs;
   float scale, keep_scale;
   uint32_t thr;
   GctRng rng;
-#ifdef GCT_STAMPS
-  unsigned long long* stamps;
-#endif
 };
-
-#ifdef GCT_STAMPS
-#define ASTAMP(i)                                                                      \
-  do {                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-    unsigned long long t__;                                                            \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");         \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-    seg[i] += t__ - tprev;                                                             \
-    tprev = t__;                                                                       \
-  } while (0)
-#else
-#define ASTAMP(i)
-#endif
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// Staging of a [B][L][ld] head slice into LDS [LP][SD] (zero padded, optional scale) is split
-// in two halves so a kernel can put ALL its global loads (q, k, v, dO, mask bytes) in flight
-// before the first LDS store: one exposed HBM/L2 latency per workgroup instead of one per
-// tensor (s_memtime stamps: 14.7k -> ~5k cycles for the forward prologue).
-template <int DK, int NTHR>
+// Staging of a [B][L][ld] head slice into LDS [LP][SD] (zero padded, optional scale) is split in a load half
+// (registers) and a store half, so the loads of the NEXT pair can be in flight during the MFMAs of this one.
+template <int DK, int NT>
 struct Stage {
   static constexpr int SD = DK + 4, C = DK / 4;
-  static constexpr int ITERS = (16 * NT_MAX * C + NTHR - 1) / NTHR;
+  static constexpr int ITERS = (16 * NT * C + ATT_THREADS - 1) / ATT_THREADS;
   float4 v[ITERS];
   __device__ __forceinline__ void load(const float* src, int64_t ld, int b, int h, int L, int tid) {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-      const int idx = tid + it * NTHR;
+      const int idx = tid + it * ATT_THREADS;
       const int r = idx / C, c = idx - r * C;
       v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r < L) v[it] = *reinterpret_cast<const float4*>(src + ((int64_t)b * L + r) * ld + h * DK + c * 4);
@@ -92,7 +84,7 @@ struct Stage {
   __device__ __forceinline__ void store(float* dst, int LP, float scale, int tid) const {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-      const int idx = tid + it * NTHR;
+      const int idx = tid + it * ATT_THREADS;
       const int r = idx / C, c = idx - r * C;
       if (r < LP) {
         float4 w = v[it];
@@ -103,95 +95,29 @@ struct Stage {
   }
 };
 
-// flags[q][k]: bit2 in range, bit0 not masked, bit1 dropout keep. One Philox call per (q, 4 keys).
-template <int NTHR>
-struct Flags {
-  static constexpr int ITERS = (16 * NT_MAX * 4 * NT_MAX + NTHR - 1) / NTHR;
-  uint32_t mv[ITERS];
-  __device__ __forceinline__ void load(const AttnArgs& a, int b, int LQP, int LKP, int tid);
-  __device__ __forceinline__ void build(uint32_t* flags32, const AttnArgs& a, int b, int h, int LQP,
-                                        int LKP, int tid) const;
-};
-
-template <int NTHR>
-__device__ __forceinline__ void Flags<NTHR>::load(const AttnArgs& a, int b, int LQP, int LKP, int tid) {
-  const int KG = LKP / 4;
-  // all mask bytes in flight (4 consecutive bytes per item, packed into one word)
-#pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    const int idx = tid + it * NTHR;
-    const int q = idx / KG, kg = idx - q * KG;
-    uint32_t w = 0x01010101u;
-    if (a.mask && q < a.Lq && idx < LQP * KG) {
-      const uint8_t* mp = a.mask + (int64_t)b * a.mask_sb + (int64_t)q * a.mask_sq + kg * 4;
-      w = 0;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (kg * 4 + e < a.Lk) w |= (mp[e] ? 1u : 0u) << (8 * e);
-    }
-    mv[it] = w;
-  }
-}
-
-template <int NTHR>
-__device__ __forceinline__ void Flags<NTHR>::build(uint32_t* flags32, const AttnArgs& a, int b, int h,
-                                                   int LQP, int LKP, int tid) const {
-  const int KG = LKP / 4;
-#pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    const int idx = tid + it * NTHR;
-    if (idx >= LQP * KG) continue;
-    const int q = idx / KG, kg = idx - q * KG;
-    uint32_t w = 0;
-    if (q < a.Lq) {
-      uint4 bits = make_uint4(~0u, ~0u, ~0u, ~0u);
-      if (a.thr)
-        bits = gct_philox(a.rng, (uint32_t)(((int64_t)b * a.H + h) * a.Lq + q), (uint32_t)kg,
-                          0xA4093822u, 0x299F31D0u);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (kg * 4 + e < a.Lk) {
-          uint32_t f = 4u | ((mv[it] >> (8 * e)) & 1u);
-          if (gct_pick(bits, e) >= a.thr) f |= 2u;
-          w |= f << (8 * e);
-        }
-      }
-    }
-    flags32[idx] = w;
-  }
-}
-
-// rowok[q] = row q has at least one visible key (or is a padding row);
-// tile_any[u*NT_MAX+t] = tile (u,t) has at least one visible (q,k).  Needs a barrier after.
-template <int NTHR>
-__device__ __forceinline__ void build_tile_maps(const uint32_t* flags32, uint8_t* rowok,
-                                                uint8_t* tile_any, int Lq, int LQP, int LKP, int tid) {
-  const int KG = LKP / 4, nkt = LKP / 16, nqt = LQP / 16;
-  for (int q = tid; q < LQP; q += NTHR) {
-    uint32_t any = 0;
-    for (int kg = 0; kg < KG; ++kg) any |= flags32[q * KG + kg] & 0x01010101u;
-    rowok[q] = (q >= Lq) || any != 0;
-  }
-  for (int ti = tid; ti < nqt * nkt; ti += NTHR) {
-    const int u = ti / nkt, t = ti - u * nkt;
-    uint32_t any = 0;
-    for (int r = 0; r < 16; ++r)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) any |= flags32[(16 * u + r) * KG + 4 * t + j] & 0x01010101u;
-    tile_any[u * NT_MAX + t] = any != 0;
-  }
-}
-
 // Operand fragments for products that contract over the head dimension (S = Q K^T, dP = dO V^T):
 // lane group g owns dk indices [g*DK/4, (g+1)*DK/4), so a lane's whole fragment of one row is
-// NDT consecutive float4 -- NDT ds_read_b128 feed DK/4 MFMAs (any k permutation is legal when
-// both operands use it).  Was: one ds_read_b32 round trip per MFMA (10.8k cycles per 80 MFMAs).
+// NDT consecutive float4 -- NDT 16-byte reads feed DK/4 MFMAs (any k permutation is legal when
+// both operands use it).
 template <int NDT>
 __device__ __forceinline__ void row_frag(float4 (&f)[NDT], const float* lds, int row, int g) {
   constexpr int SD = 16 * NDT + 4;
 #pragma unroll
   for (int j = 0; j < NDT; ++j)
     f[j] = *reinterpret_cast<const float4*>(lds + row * SD + g * 4 * NDT + 4 * j);
+}
+// the same fragment straight from global memory (row of a [B][L][ld] head slice), zero beyond L
+template <int NDT>
+__device__ __forceinline__ void row_frag_global(float4 (&f)[NDT], const float* src, int64_t ld, int b, int h, int L,
+                                                int row, int g, float scale) {
+#pragma unroll
+  for (int j = 0; j < NDT; ++j) {
+    f[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < L) {
+      f[j] = *reinterpret_cast<const float4*>(src + ((int64_t)b * L + row) * ld + h * 16 * NDT + g * 4 * NDT + 4 * j);
+      f[j].x *= scale; f[j].y *= scale; f[j].z *= scale; f[j].w *= scale;
+    }
+  }
 }
 template <int NDT>
 __device__ __forceinline__ f32x4 dot_frag(const float4 (&a)[NDT], const float4 (&b)[NDT], f32x4 acc) {
@@ -205,297 +131,311 @@ __device__ __forceinline__ f32x4 dot_frag(const float4 (&a)[NDT], const float4 (
   return acc;
 }
 
-// bit t set => key tile t must be computed for query tile u
-__device__ __forceinline__ uint32_t tiles_for_q(const uint8_t* rowok, const uint8_t* tile_any, int u,
-                                                int nkt, int c16) {
-  const bool ok = __all(rowok[16 * u + c16] != 0);
+// bits of word w (keys 32w .. 32w+31) that are inside [0, Lk)
+__device__ __forceinline__ uint32_t range_word(int w, int Lk) {
+  const int n = Lk - 32 * w;
+  return n >= 32 ? 0xffffffffu : (n > 0 ? ((1u << n) - 1u) : 0u);
+}
+
+// packed mask words of query row q (all ones without a mask or beyond Lq)
+template <int MW>
+__device__ __forceinline__ void mask_row(uint32_t (&mw)[MW], const AttnArgs& a, int b, int q) {
+#pragma unroll
+  for (int w = 0; w < MW; ++w) mw[w] = 0xffffffffu;
+  if (a.mbits && q < a.Lq) {
+    const uint4* p = reinterpret_cast<const uint4*>(a.mbits + (int64_t)b * a.mb_sb + (int64_t)q * a.mb_sq);
+#pragma unroll
+    for (int w4 = 0; w4 < (MW + 3) / 4; ++w4) {
+      const uint4 x = p[w4];
+      if (4 * w4 + 0 < MW) mw[4 * w4 + 0] = x.x;
+      if (4 * w4 + 1 < MW) mw[4 * w4 + 1] = x.y;
+      if (4 * w4 + 2 < MW) mw[4 * w4 + 2] = x.z;
+      if (4 * w4 + 3 < MW) mw[4 * w4 + 3] = x.w;
+    }
+  }
+}
+
+// bit t set => key tile t must be computed for the query tile whose row `q` this lane holds (mw = its mask words)
+template <int MW>
+__device__ __forceinline__ uint32_t tiles_for_q(const uint32_t (&mw)[MW], int q, int Lq, int Lk, int nkt) {
+  uint32_t rowvis = 0;
+#pragma unroll
+  for (int w = 0; w < MW; ++w) rowvis |= mw[w] & range_word(w, Lk);
+  const bool real = q < Lq;
+  const bool ok = __all(!real || rowvis != 0);      // every real row of the tile sees a key
   uint32_t use = 0;
-  for (int t = 0; t < nkt; ++t)
-    if (!ok || tile_any[u * NT_MAX + t]) use |= 1u << t;
+#pragma unroll
+  for (int t = 0; t < 2 * MW; ++t)
+    if (t < nkt) {
+      const uint32_t nib = ((mw[t >> 1] & range_word(t >> 1, Lk)) >> ((t & 1) * 16)) & 0xffffu;
+      if (!ok || __any(real && nib != 0)) use |= 1u << t;
+    }
   return __builtin_amdgcn_readfirstlane(use);
 }
 
-__device__ __forceinline__ float score_of(float s, uint32_t f) {
-  return (f & 4u) ? ((f & 1u) ? s : -1e9f) : -INFINITY;
+__device__ __forceinline__ float score_of(float s, bool in_range, bool visible) {
+  return in_range ? (visible ? s : -1e9f) : -INFINITY;
 }
 
 // ------------------------------------------------------------------------------ forward
-template <int NDT>
-__global__ __launch_bounds__(FWD_THREADS) void attn_fwd_kernel(const AttnArgs a) {
-  constexpr int DK = 16 * NDT, SD = DK + 4, NW = FWD_THREADS / 64;
+// One query tile (16 rows) of one pair: S^T, softmax, P.V.  bq = this lane's (pre-scaled) Q fragment.
+template <int NDT, int NT, typename AfterS>
+__device__ __forceinline__ void fwd_unit(const AttnArgs& a, int b, int h, int u, float4 (&bq)[NDT],
+                                         const float* Ks, const float* Vs, int nkt, int lane, AfterS after_s) {
+  constexpr int DK = 16 * NDT, SD = DK + 4, MW = (NT + 1) / 2;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int q = 16 * u + c16;
+  uint32_t mw[MW];
+  mask_row<MW>(mw, a, b, q);
+  const uint32_t use = tiles_for_q<MW>(mw, q, a.Lq, a.Lk, nkt);
+  f32x4 sacc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // S^T[k][q] = sum_d K[k][d] * Qs[q][d]
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if ((use >> t) & 1u) {
+      float4 ak[NDT];
+      row_frag<NDT>(ak, Ks, 16 * t + c16, g);
+      sacc[t] = dot_frag<NDT>(ak, bq, sacc[t]);
+    }
+  after_s();          // bq is dead from here on: the caller may reload it (next pair's rows)
+  // mask + softmax over keys (regs x tiles in-lane, then lanes l^16, l^32)
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if (t < nkt) {
+      const uint32_t nib = mw[t >> 1] >> ((t & 1) * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sv = score_of(sacc[t][r], 16 * t + 4 * g + r < a.Lk, (nib >> r) & 1u);
+        sacc[t][r] = sv;
+        m = fmaxf(m, sv);
+      }
+    }
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  if (m == -INFINITY) m = 0.f;
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if (t < nkt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(sacc[t][r] - m);
+        sacc[t][r] = e;
+        l += e;
+      }
+    }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  const int64_t grow = ((int64_t)b * a.H + h) * a.Lq + q;
+  if (g == 0 && q < a.Lq) a.lse[grow] = m + __logf(l);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if (t < nkt) {
+      uint4 bits = make_uint4(~0u, ~0u, ~0u, ~0u);
+      if (a.thr && ((use >> t) & 1u)) bits = gct_philox(a.rng, (uint32_t)grow, (uint32_t)(4 * t + g), 0xA4093822u, 0x299F31D0u);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = sacc[t][r] * inv;
+        const int k = 16 * t + 4 * g + r;
+        if (a.probs && q < a.Lq && k < a.Lk) a.probs[grow * a.Lk + k] = p;
+        sacc[t][r] = (gct_pick(bits, r) >= a.thr) ? p * a.keep_scale : 0.f;
+      }
+    }
+  // O^T[d][q] = sum_k V[k][d] * Pdrop^T[k][q]
+  f32x4 oacc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if ((use >> t) & 1u) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float bp = sacc[t][r];
+        const float* vrow = Vs + (16 * t + 4 * g + r) * SD + c16;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) oacc[dt] = mfma16(vrow[16 * dt], bp, oacc[dt]);
+      }
+    }
+  if (q < a.Lq) {
+    float* orow = a.o + ((int64_t)b * a.Lq + q) * a.ldo + h * DK + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+      *reinterpret_cast<float4*>(orow + 16 * dt) = make_float4(oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]);
+  }
+}
+
+template <int NDT, int NT, bool PIPE>
+__global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_fwd_kernel(const AttnArgs a) {
+  constexpr int DK = 16 * NDT, SD = DK + 4, NW = ATT_THREADS / 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
-  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
-  const int LQP = (a.Lq + 15) & ~15, LKP = (a.Lk + 15) & ~15, nkt = LKP / 16, KG = LKP / 4;
-  // Q is only ever a B-operand fragment of its own query row: it is read straight from global
-  // memory into registers (no LDS copy => 50 KB per workgroup at L=80, 3 workgroups per CU)
+  const int LQP = (a.Lq + 15) & ~15, LKP = (a.Lk + 15) & ~15, nkt = LKP / 16, nqt = LQP / 16;
   float* Ks = smem;
   float* Vs = Ks + LKP * SD;
-  uint32_t* flags32 = reinterpret_cast<uint32_t*>(Vs + LKP * SD);
-  uint8_t* rowok = reinterpret_cast<uint8_t*>(flags32 + LQP * KG);
-  uint8_t* tile_any = rowok + 16 * NT_MAX;
-#ifdef GCT_STAMPS
-  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
-#endif
+  int pair = blockIdx.x;
+  if (pair >= a.npairs) return;
+  Stage<DK, NT> sk, sv;
+  float4 bq[NDT];
   {
-    Stage<DK, FWD_THREADS> sk, sv;
-    Flags<FWD_THREADS> fl;
+    const int b = pair / a.H, h = pair - b * a.H;
     sk.load(a.k, a.ldk, b, h, a.Lk, tid);
     sv.load(a.v, a.ldv, b, h, a.Lk, tid);
-    fl.load(a, b, LQP, LKP, tid);
+    row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, 16 * wave + c16, g, a.scale);
+  }
+  for (;;) {
+    const int b = pair / a.H, h = pair - b * a.H;
     sk.store(Ks, LKP, 1.0f, tid);
     sv.store(Vs, LKP, 1.0f, tid);
-    ASTAMP(0);  // staging q,k,v
-    fl.build(flags32, a, b, h, LQP, LKP, tid);
+    __syncthreads();
+    const int next = pair + (int)gridDim.x;
+    const bool more = next < a.npairs;
+    const int nb = more ? next / a.H : 0, nh = more ? next - nb * a.H : 0;
+    if (PIPE && more) {                  // next pair's K and V: in flight during the MFMAs below
+      sk.load(a.k, a.ldk, nb, nh, a.Lk, tid);
+      sv.load(a.v, a.ldv, nb, nh, a.Lk, tid);
+    }
+    for (int u = wave; u < nqt; u += NW) {
+      if (u != wave) row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, 16 * u + c16, g, a.scale);
+      const bool last = u + NW >= nqt;
+      fwd_unit<NDT, NT>(a, b, h, u, bq, Ks, Vs, nkt, lane, [&]() {
+        // S^T was bq's last use: this wave's Q rows of the next pair arrive during softmax and P.V
+        if (PIPE && more && last) row_frag_global<NDT>(bq, a.q, a.ldq, nb, nh, a.Lq, 16 * wave + c16, g, a.scale);
+      });
+    }
+    if (PIPE && more && wave >= nqt) row_frag_global<NDT>(bq, a.q, a.ldq, nb, nh, a.Lq, 16 * wave + c16, g, a.scale);
+    if (next >= a.npairs) break;
+    __syncthreads();                     // every wave is done reading Ks / Vs
+    if (!PIPE) {
+      sk.load(a.k, a.ldk, nb, nh, a.Lk, tid);
+      sv.load(a.v, a.ldv, nb, nh, a.Lk, tid);
+      row_frag_global<NDT>(bq, a.q, a.ldq, nb, nh, a.Lq, 16 * wave + c16, g, a.scale);
+    }
+    pair = next;
   }
-  __syncthreads();
-  ASTAMP(1);  // flags + barrier
-  build_tile_maps<FWD_THREADS>(flags32, rowok, tile_any, a.Lq, LQP, LKP, tid);
-  __syncthreads();
-  ASTAMP(2);  // tile maps + barrier
-
-  // this wave's query fragment (first tile) is requested before the barriers above would let
-  // it be consumed, so its latency overlaps the K/V staging
-  for (int u = wave; u < LQP / 16; u += NW) {
-    const int q = 16 * u + c16;
-    float4 bq[NDT];
-#pragma unroll
-    for (int j = 0; j < NDT; ++j) {
-      bq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (q < a.Lq) {
-        bq[j] = *reinterpret_cast<const float4*>(a.q + ((int64_t)b * a.Lq + q) * a.ldq + h * DK +
-                                                 g * 4 * NDT + 4 * j);
-        bq[j].x *= a.scale; bq[j].y *= a.scale; bq[j].z *= a.scale; bq[j].w *= a.scale;
-      }
-    }
-    const uint32_t use = tiles_for_q(rowok, tile_any, u, nkt, c16);
-    f32x4 sacc[NT_MAX];
-#pragma unroll
-    for (int t = 0; t < NT_MAX; ++t) sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // S^T[k][q] = sum_d K[k][d] * Qs[q][d]
-    {
-#pragma unroll
-      for (int t = 0; t < NT_MAX; ++t)
-        if ((use >> t) & 1u) {
-          float4 ak[NDT];
-          row_frag<NDT>(ak, Ks, 16 * t + c16, g);
-          sacc[t] = dot_frag<NDT>(ak, bq, sacc[t]);
-        }
-    }
-    ASTAMP(3);  // S = K Q^T
-    // mask + softmax over keys (regs x tiles in-lane, then lanes l^16, l^32)
-    uint32_t fw[NT_MAX];
-    float m = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < NT_MAX; ++t) {
-      fw[t] = 0;
-      if (t < nkt) {
-        fw[t] = flags32[q * KG + 4 * t + g];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sv = score_of(sacc[t][r], (fw[t] >> (8 * r)) & 0xffu);
-          sacc[t][r] = sv;
-          m = fmaxf(m, sv);
-        }
-      }
-    }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    if (m == -INFINITY) m = 0.f;
-    float l = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT_MAX; ++t)
-      if (t < nkt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __expf(sacc[t][r] - m);
-          sacc[t][r] = e;
-          l += e;
-        }
-      }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
-    const int64_t grow = ((int64_t)b * a.H + h) * a.Lq + q;
-    if (g == 0 && q < a.Lq) a.lse[grow] = m + __logf(l);
-#pragma unroll
-    for (int t = 0; t < NT_MAX; ++t)
-      if (t < nkt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = sacc[t][r] * inv;
-          const int k = 16 * t + 4 * g + r;
-          if (a.probs && q < a.Lq && k < a.Lk) a.probs[grow * a.Lk + k] = p;
-          sacc[t][r] = ((fw[t] >> (8 * r)) & 2u) ? p * a.keep_scale : 0.f;
-        }
-      }
-    ASTAMP(4);  // softmax
-    // O^T[d][q] = sum_k V[k][d] * Pdrop^T[k][q]
-    f32x4 oacc[NDT];
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < NT_MAX; ++t)
-      if ((use >> t) & 1u) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float bp = sacc[t][r];
-          const float* vrow = Vs + (16 * t + 4 * g + r) * SD + c16;
-#pragma unroll
-          for (int dt = 0; dt < NDT; ++dt) oacc[dt] = mfma16(vrow[16 * dt], bp, oacc[dt]);
-        }
-      }
-    if (q < a.Lq) {
-      float* orow = a.o + ((int64_t)b * a.Lq + q) * a.ldo + h * DK + 4 * g;
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt)
-        *reinterpret_cast<float4*>(orow + 16 * dt) =
-            make_float4(oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]);
-    }
-    ASTAMP(5);  // P.V + store
-  }
-#ifdef GCT_STAMPS
-  if (a.stamps && lane == 0 && blockIdx.x < 64)
-    for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * NW + wave) * 8 + i] = seg[i];
-#endif
 }
 
 // ----------------------------------------------------------------------------- backward
-template <int NDT>
-__global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a) {
-  constexpr int DK = 16 * NDT, SD = DK + 4, NW = BWD_THREADS / 64;
+template <int NDT, int NT>
+__global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kernel(const AttnArgs a) {
+  constexpr int DK = 16 * NDT, SD = DK + 4, NW = ATT_THREADS / 64, MW = (NT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
-  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
-  const int LQP = (a.Lq + 15) & ~15, LKP = (a.Lk + 15) & ~15, nkt = LKP / 16, nqt = LQP / 16,
-            KG = LKP / 4;
-  float* Qs = smem;               // scaled by `scale`
-  float* Ks = Qs + LQP * SD;
-  float* Vs = Ks + LKP * SD;
-  float* dOs = Vs + LKP * SD;
-  float* lse_s = dOs + LQP * SD;  // [LQP]
-  float* del_s = lse_s + LQP;     // [LQP]
-  uint32_t* flags32 = reinterpret_cast<uint32_t*>(del_s + LQP);
-  const uint8_t* flags8 = reinterpret_cast<const uint8_t*>(flags32);
-  uint8_t* rowok = reinterpret_cast<uint8_t*>(flags32 + LQP * KG);
-  uint8_t* tile_any = rowok + 16 * NT_MAX;
-  uint8_t* rowlive = tile_any + NT_MAX * NT_MAX;   // dO row has a non-zero element
-#ifdef GCT_STAMPS
-  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
-#endif
-  {
-    Stage<DK, BWD_THREADS> sq, sk, sv, sd;
-    Flags<BWD_THREADS> fl;
-    sq.load(a.q, a.ldq, b, h, a.Lq, tid);
-    sk.load(a.k, a.ldk, b, h, a.Lk, tid);
-    sv.load(a.v, a.ldv, b, h, a.Lk, tid);
-    sd.load(a.dout, a.ldo, b, h, a.Lq, tid);
-    fl.load(a, b, LQP, LKP, tid);
-    sq.store(Qs, LQP, a.scale, tid);
-    sk.store(Ks, LKP, 1.0f, tid);
-    sv.store(Vs, LKP, 1.0f, tid);
-    sd.store(dOs, LQP, 1.0f, tid);
-    fl.build(flags32, a, b, h, LQP, LKP, tid);
-  }
-  ASTAMP(0);  // staging + flags
-  // delta[q] = sum_d dO[q][d] * O[q][d]  (16 lanes per row)
-  // rowlive[q]: the incoming gradient row is not identically zero.  A query tile whose 16 rows are all
-  // zero (padded target positions under an ignore_index loss) contributes exactly nothing: dP = 0,
-  // delta = 0 => dS = 0 => dQ rows = 0 and no dK / dV contribution -- such tiles are skipped below.
-  for (int r0 = tid >> 4; r0 < LQP; r0 += BWD_THREADS / 16) {
-    float acc = 0.f;
-    int nz = 0;
-    if (r0 < a.Lq) {
-      const float* orow = a.o_in + ((int64_t)b * a.Lq + r0) * a.ldo + h * DK;
-      const float* drow = a.dout + ((int64_t)b * a.Lq + r0) * a.ldo + h * DK;
-      for (int c = (tid & 15) * 4; c < DK; c += 64) {
-        const float4 x = *reinterpret_cast<const float4*>(orow + c);
-        const float4 y = *reinterpret_cast<const float4*>(drow + c);
-        acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
-        nz |= (y.x != 0.f) | (y.y != 0.f) | (y.z != 0.f) | (y.w != 0.f);
+  const int LQP = (a.Lq + 15) & ~15, LKP = (a.Lk + 15) & ~15, nkt = LKP / 16, nqt = LQP / 16;
+  const int LMX = LQP > LKP ? LQP : LKP;
+  // region 0 holds {K, V} in phase A and {Q (scaled), dO} in phase B
+  float* R0 = smem;
+  float* R1 = R0 + LMX * SD;
+  float* lse_s = R1 + LMX * SD;                                   // [LQP]
+  float* del_s = lse_s + LQP;                                     // [LQP]
+  uint32_t* mb_s = reinterpret_cast<uint32_t*>(del_s + LQP);      // [LQP][MW] packed mask rows
+  uint32_t* kp_s = mb_s + LQP * MW;                               // [LQP][MW] dropout keep bits
+  uint8_t* rowok = reinterpret_cast<uint8_t*>(kp_s + LQP * MW);   // [LQP] row sees a key (or is padding)
+  uint8_t* rowlive = rowok + LQP;                                 // [LQP] dO row has a non-zero element
+  for (int pair = blockIdx.x; pair < a.npairs; pair += (int)gridDim.x) {
+    const int b = pair / a.H, h = pair - b * a.H;
+    const int64_t lrow0 = ((int64_t)b * a.H + h) * a.Lq;
+    // ---------------------------------------------------------------- phase A: K, V in LDS -> dQ
+    {
+      Stage<DK, NT> sk, sv;
+      sk.load(a.k, a.ldk, b, h, a.Lk, tid);
+      sv.load(a.v, a.ldv, b, h, a.Lk, tid);
+      // packed mask rows and "row sees a key" (both phases read them from LDS)
+      for (int q = tid; q < LQP; q += ATT_THREADS) {
+        uint32_t mw[MW];
+        mask_row<MW>(mw, a, b, q);
+        uint32_t vis = 0;
+#pragma unroll
+        for (int w = 0; w < MW; ++w) {
+          mb_s[q * MW + w] = mw[w];
+          vis |= mw[w] & range_word(w, a.Lk);
+        }
+        rowok[q] = (q >= a.Lq) || vis != 0;
       }
+      sk.store(R0, LKP, 1.0f, tid);
+      sv.store(R1, LKP, 1.0f, tid);
     }
-    acc += __shfl_xor(acc, 8, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 1, 64);
-    nz |= __shfl_xor(nz, 8, 64);
-    nz |= __shfl_xor(nz, 4, 64);
-    nz |= __shfl_xor(nz, 2, 64);
-    nz |= __shfl_xor(nz, 1, 64);
-    if ((tid & 15) == 0) {
-      del_s[r0] = acc;
-      lse_s[r0] = r0 < a.Lq ? a.lse_in[((int64_t)b * a.H + h) * a.Lq + r0] : 0.f;
-      rowlive[r0] = (uint8_t)nz;
-    }
-  }
-  __syncthreads();
-  ASTAMP(1);  // delta + barrier
-  build_tile_maps<BWD_THREADS>(flags32, rowok, tile_any, a.Lq, LQP, LKP, tid);
-  __syncthreads();
-  ASTAMP(2);  // maps + barrier
-
-  // work units 0..nqt-1 = pass A (query tiles), nqt..nqt+nkt-1 = pass B (key tiles)
-  for (int unit = wave; unit < nqt + nkt; unit += NW) {
-    if (unit < nqt) {
-      // ---- pass A: dQ for query tile u; key index on registers.
-      const int u = unit, q = 16 * u + c16;
-      if (!__any(rowlive[q] != 0)) {            // all 16 gradient rows are zero: dQ rows = 0, nothing else
+    __syncthreads();
+    for (int u = wave; u < nqt; u += NW) {
+      const int q = 16 * u + c16;
+      float4 bq[NDT], bd[NDT];
+      row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, q, g, a.scale);
+      row_frag_global<NDT>(bd, a.dout, a.ldo, b, h, a.Lq, q, g, 1.0f);
+      float del = 0.f;
+      int nz = 0;
+      {
+        float4 bo[NDT];
+        row_frag_global<NDT>(bo, a.o_in, a.ldo, b, h, a.Lq, q, g, 1.0f);
+#pragma unroll
+        for (int j = 0; j < NDT; ++j) {
+          del += (bo[j].x * bd[j].x + bo[j].y * bd[j].y) + (bo[j].z * bd[j].z + bo[j].w * bd[j].w);
+          nz |= (bd[j].x != 0.f) | (bd[j].y != 0.f) | (bd[j].z != 0.f) | (bd[j].w != 0.f);
+        }
+      }
+      del += __shfl_xor(del, 16, 64);
+      del += __shfl_xor(del, 32, 64);
+      nz |= __shfl_xor(nz, 16, 64);
+      nz |= __shfl_xor(nz, 32, 64);
+      const float lse = q < a.Lq ? a.lse_in[lrow0 + q] : 0.f;
+      if (g == 0) {
+        del_s[q] = del;
+        lse_s[q] = lse;
+        rowlive[q] = (uint8_t)nz;
+      }
+      if (!__any(nz)) {                       // all 16 gradient rows are zero: dQ rows = 0, nothing else
         if (q < a.Lq) {
           float* drow = a.dq + ((int64_t)b * a.Lq + q) * a.lddq + h * DK + 4 * g;
 #pragma unroll
-          for (int dt = 0; dt < NDT; ++dt)
-            *reinterpret_cast<float4*>(drow + 16 * dt) = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int dt = 0; dt < NDT; ++dt) *reinterpret_cast<float4*>(drow + 16 * dt) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        ASTAMP(3);
         continue;
       }
-      const uint32_t use = tiles_for_q(rowok, tile_any, u, nkt, c16);
-      f32x4 sacc[NT_MAX], pacc[NT_MAX];
+      uint32_t mw[MW];
 #pragma unroll
-      for (int t = 0; t < NT_MAX; ++t) {
+      for (int w = 0; w < MW; ++w) mw[w] = mb_s[q * MW + w];
+      const uint32_t use = tiles_for_q<MW>(mw, q, a.Lq, a.Lk, nkt);
+      f32x4 sacc[NT];                       // ends up holding dS^T
+      const int64_t grow = lrow0 + q;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
         sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        pacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-      {
-        float4 bq[NDT], bd[NDT];
-        row_frag<NDT>(bq, Qs, q, g);
-        row_frag<NDT>(bd, dOs, q, g);
-#pragma unroll
-        for (int t = 0; t < NT_MAX; ++t)
-          if ((use >> t) & 1u) {
-            float4 ak[NDT], av[NDT];
-            row_frag<NDT>(ak, Ks, 16 * t + c16, g);
-            row_frag<NDT>(av, Vs, 16 * t + c16, g);
-            sacc[t] = dot_frag<NDT>(ak, bq, sacc[t]);  // S^T
-            pacc[t] = dot_frag<NDT>(av, bd, pacc[t]);  // dP^T
-          }
-      }
-      const float lse = lse_s[q], del = del_s[q];
-#pragma unroll
-      for (int t = 0; t < NT_MAX; ++t)
         if ((use >> t) & 1u) {
-          const uint32_t w = flags32[q * KG + 4 * t + g];
+          f32x4 pacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+          {
+            float4 ak[NDT];
+            row_frag<NDT>(ak, R0, 16 * t + c16, g);
+            sacc[t] = dot_frag<NDT>(ak, bq, sacc[t]);  // S^T
+          }
+          {
+            float4 av[NDT];
+            row_frag<NDT>(av, R1, 16 * t + c16, g);
+            pacc = dot_frag<NDT>(av, bd, pacc);        // dP^T
+          }
+          const uint32_t nib = mw[t >> 1] >> ((t & 1) * 16 + 4 * g);
+          uint4 bits = make_uint4(~0u, ~0u, ~0u, ~0u);
+          if (a.thr) bits = gct_philox(a.rng, (uint32_t)grow, (uint32_t)(4 * t + g), 0xA4093822u, 0x299F31D0u);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const uint32_t f = (w >> (8 * r)) & 0xffu;
-            const float p = (f & 4u) ? __expf(score_of(sacc[t][r], f) - lse) : 0.f;
-            const float dpd = (f & 2u) ? pacc[t][r] * a.keep_scale : 0.f;
-            sacc[t][r] = (f & 1u) ? p * (dpd - del) : 0.f;  // dS^T (masked_fill passes no grad)
+            const bool inr = 16 * t + 4 * g + r < a.Lk, vis = (nib >> r) & 1u;
+            const float p = inr ? __expf(score_of(sacc[t][r], true, vis) - lse) : 0.f;
+            const float dpd = (gct_pick(bits, r) >= a.thr) ? pacc[r] * a.keep_scale : 0.f;
+            sacc[t][r] = vis ? p * (dpd - del) : 0.f;  // dS^T (masked_fill passes no grad)
           }
         }
+      }
       f32x4 qacc[NDT];
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) qacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < NT_MAX; ++t)
+      for (int t = 0; t < NT; ++t)
         if ((use >> t) & 1u) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float bs = sacc[t][r];
-            const float* krow = Ks + (16 * t + 4 * g + r) * SD + c16;
+            const float* krow = R0 + (16 * t + 4 * g + r) * SD + c16;
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) qacc[dt] = mfma16(krow[16 * dt], bs, qacc[dt]);
           }
@@ -505,12 +445,41 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
           *reinterpret_cast<float4*>(drow + 16 * dt) =
-              make_float4(qacc[dt][0] * a.scale, qacc[dt][1] * a.scale, qacc[dt][2] * a.scale,
-                          qacc[dt][3] * a.scale);
+              make_float4(qacc[dt][0] * a.scale, qacc[dt][1] * a.scale, qacc[dt][2] * a.scale, qacc[dt][3] * a.scale);
       }
-    } else {
-      // ---- pass B: dK, dV for key tile t; query index on registers.
-      const int t = unit - nqt, k = 16 * t + c16;
+    }
+    __syncthreads();      // K, V no longer needed; del_s / lse_s / rowlive complete
+    // ---------------------------------------------------------------- phase B: Q, dO in LDS -> dK, dV
+    {
+      Stage<DK, NT> sq, sd;
+      sq.load(a.q, a.ldq, b, h, a.Lq, tid);          // second read of this pair's Q / dO: L2
+      sd.load(a.dout, a.ldo, b, h, a.Lq, tid);
+      if (a.thr) {
+        // keep bits of (q, 32 keys): 8 Philox calls, the same (row, 4-key group) counters as phase A / forward
+        for (int i = tid; i < LQP * MW; i += ATT_THREADS) {
+          const int q = i / MW, w = i - q * MW;
+          uint32_t word = 0;
+          if (q < a.Lq && rowlive[q]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int kg = 8 * w + e;
+              if (4 * kg < a.Lk) {
+                const uint4 bits = gct_philox(a.rng, (uint32_t)(lrow0 + q), (uint32_t)kg, 0xA4093822u, 0x299F31D0u);
+                const uint32_t nibk = (bits.x >= a.thr ? 1u : 0u) | (bits.y >= a.thr ? 2u : 0u) |
+                                      (bits.z >= a.thr ? 4u : 0u) | (bits.w >= a.thr ? 8u : 0u);
+                word |= nibk << (4 * e);
+              }
+            }
+          }
+          kp_s[i] = word;
+        }
+      }
+      sq.store(R0, LQP, a.scale, tid);
+      sd.store(R1, LQP, 1.0f, tid);
+    }
+    __syncthreads();
+    for (int t = wave; t < nkt; t += NW) {
+      const int k = 16 * t + c16;
       f32x4 vacc[NDT], kacc[NDT];
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
@@ -518,18 +487,27 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
         kacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
       float4 bk[NDT], bv[NDT];
-      row_frag<NDT>(bk, Ks, k, g);
-      row_frag<NDT>(bv, Vs, k, g);
+      row_frag_global<NDT>(bk, a.k, a.ldk, b, h, a.Lk, k, g, 1.0f);
+      row_frag_global<NDT>(bv, a.v, a.ldv, b, h, a.Lk, k, g, 1.0f);
+      const int kw = k >> 5, kb = k & 31;
+      const bool inr = k < a.Lk;
 #pragma unroll 1
       for (int u = 0; u < nqt; ++u) {
         if (!__any(rowlive[16 * u + c16] != 0)) continue;  // zero gradient rows: Pd^T dO = 0 and dS = 0
+        uint32_t vis4 = 0, keep4 = 0xfu;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qq = 16 * u + 4 * g + r;
+          vis4 |= ((mb_s[qq * MW + kw] >> kb) & 1u) << r;
+          if (a.thr) keep4 = (keep4 & ~(1u << r)) | (((kp_s[qq * MW + kw] >> kb) & 1u) << r);
+        }
         const bool ok = __all(rowok[16 * u + c16] != 0);
-        if (ok && !tile_any[u * NT_MAX + t]) continue;  // fully masked tile: P = dS = 0
+        if (ok && !__any(inr && vis4 != 0)) continue;       // fully masked tile: P = dS = 0
         f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, pa = (f32x4){0.f, 0.f, 0.f, 0.f};
         {
           float4 aq[NDT], ad[NDT];
-          row_frag<NDT>(aq, Qs, 16 * u + c16, g);
-          row_frag<NDT>(ad, dOs, 16 * u + c16, g);
+          row_frag<NDT>(aq, R0, 16 * u + c16, g);
+          row_frag<NDT>(ad, R1, 16 * u + c16, g);
           sa = dot_frag<NDT>(aq, bk, sa);   // S[q][k]
           pa = dot_frag<NDT>(ad, bv, pa);   // dP[q][k]
         }
@@ -537,16 +515,16 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qq = 16 * u + 4 * g + r;
-          const uint32_t f = flags8[qq * LKP + k];
-          const float p = (f & 4u) ? __expf(score_of(sa[r], f) - lse_s[qq]) : 0.f;
-          const float dpd = (f & 2u) ? pa[r] * a.keep_scale : 0.f;
-          pd[r] = (f & 2u) ? p * a.keep_scale : 0.f;
-          ds[r] = (f & 1u) ? p * (dpd - del_s[qq]) : 0.f;
+          const bool vis = (vis4 >> r) & 1u, keep = (keep4 >> r) & 1u;
+          const float p = inr ? __expf(score_of(sa[r], true, vis) - lse_s[qq]) : 0.f;
+          const float dpd = keep ? pa[r] * a.keep_scale : 0.f;
+          pd[r] = keep ? p * a.keep_scale : 0.f;
+          ds[r] = vis ? p * (dpd - del_s[qq]) : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float* dorow = dOs + (16 * u + 4 * g + r) * SD + c16;
-          const float* qrow = Qs + (16 * u + 4 * g + r) * SD + c16;
+          const float* dorow = R1 + (16 * u + 4 * g + r) * SD + c16;
+          const float* qrow = R0 + (16 * u + 4 * g + r) * SD + c16;
 #pragma unroll
           for (int dt = 0; dt < NDT; ++dt) {
             vacc[dt] = mfma16(dorow[16 * dt], pd[r], vacc[dt]);  // dV^T[d][k] += dO[q][d] Pd[q][k]
@@ -559,88 +537,152 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_bwd_kernel(const AttnArgs a)
         float* krow = a.dk + ((int64_t)b * a.Lk + k) * a.lddk + h * DK + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-          *reinterpret_cast<float4*>(vrow + 16 * dt) =
-              make_float4(vacc[dt][0], vacc[dt][1], vacc[dt][2], vacc[dt][3]);
-          *reinterpret_cast<float4*>(krow + 16 * dt) =
-              make_float4(kacc[dt][0], kacc[dt][1], kacc[dt][2], kacc[dt][3]);
+          *reinterpret_cast<float4*>(vrow + 16 * dt) = make_float4(vacc[dt][0], vacc[dt][1], vacc[dt][2], vacc[dt][3]);
+          *reinterpret_cast<float4*>(krow + 16 * dt) = make_float4(kacc[dt][0], kacc[dt][1], kacc[dt][2], kacc[dt][3]);
         }
       }
     }
-    ASTAMP(3);  // unit (pass A or pass B)
+    __syncthreads();      // before the next pair's staging overwrites the region
   }
-#ifdef GCT_STAMPS
-  if (a.stamps && lane == 0 && blockIdx.x < 64)
-    for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * NW + wave) * 8 + i] = seg[i];
-#endif
+}
+
+// one thread per packed word: bits[b][q][w] = OR_j (mask[b,q,32w+j] != 0) << j
+__global__ __launch_bounds__(256) void mask_pack_kernel(const uint8_t* __restrict__ mask, int64_t sb, int64_t sq, int B,
+                                                        int rows, int Lk, uint32_t* __restrict__ bits) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * rows * MASK_W) return;
+  const int w = (int)(i % MASK_W);
+  const int64_t br = i / MASK_W;
+  const int q = (int)(br % rows), b = (int)(br / rows);
+  const uint8_t* m = mask + (int64_t)b * sb + (int64_t)q * sq;
+  uint32_t word = 0;
+  for (int j = 0; j < 32; ++j) {
+    const int k = 32 * w + j;
+    if (k < Lk && m[k]) word |= 1u << j;
+  }
+  bits[i] = word;
+}
+
+int g_num_cus = 0;
+int num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    g_num_cus = n;
+  }
+  return g_num_cus;
 }
 
 template <typename K>
-int ensure_lds(K kernel, size_t lds, bool* done) {
-  if (lds <= 64 * 1024 || *done) return GCT_OK;
-  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024);
+int ensure_lds(K kernel, size_t lds) {
+  if (lds <= 64 * 1024) return GCT_OK;
+  // idempotent and cheap; done per launch so every instantiation / device is covered
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) {
     gct_set_error("attention: cannot opt in to 160 KB LDS: %s", hipGetErrorString(e));
     return GCT_ERR_HIP;
   }
-  *done = true;
   return GCT_OK;
 }
 
 int check_common(const char* who, const float* q, int64_t ldq, const float* k, int64_t ldk,
-                 const float* v, int64_t ldv, int B, int H, int Lq, int Lk, int dk, float p) {
+                 const float* v, int64_t ldv, const uint32_t* mbits, int64_t mb_sb, int64_t mb_sq, int B, int H,
+                 int Lq, int Lk, int dk, float p) {
   GCT_CHECK_ARG(q && k && v && B >= 0 && H > 0 && Lq > 0 && Lk > 0, "%s: bad args", who);
   GCT_CHECK_ARG(dk == 16 || dk == 32 || dk == 64, "%s: head dim %d unsupported (16/32/64)", who, dk);
-  GCT_CHECK_ARG(Lq <= 16 * NT_MAX && Lk <= 16 * NT_MAX, "%s: sequence length > %d unsupported", who,
-                16 * NT_MAX);
+  GCT_CHECK_ARG(Lq <= L_MAX && Lk <= L_MAX, "%s: sequence length > %d unsupported", who, L_MAX);
   GCT_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && gct_aligned16(q) &&
                     gct_aligned16(k) && gct_aligned16(v),
                 "%s: q/k/v must be 16-B aligned with ld %% 4 == 0", who);
+  GCT_CHECK_ARG(!mbits || (gct_aligned16(mbits) && mb_sb % 4 == 0 && mb_sq % 4 == 0),
+                "%s: packed mask rows must be 16-B aligned (use gct_attn_mask_pack)", who);
   GCT_CHECK_ARG(p >= 0.f && p < 1.f, "%s: dropout p out of range", who);
+  GCT_CHECK_ARG((int64_t)B * H <= INT32_MAX, "%s: too many (batch, head) pairs", who);
   return GCT_OK;
 }
 
-constexpr size_t MAPS_BYTES = 16 * NT_MAX + NT_MAX * NT_MAX + 16 * NT_MAX;  // rowok + tile_any + (bwd) rowlive
+template <int NDT, int NT>
+int launch_fwd(const AttnArgs& a, size_t lds, unsigned grid, hipStream_t st) {
+  constexpr bool PIPE = NT <= 8;
+  int rc = ensure_lds(attn_fwd_kernel<NDT, NT, PIPE>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((attn_fwd_kernel<NDT, NT, PIPE>), dim3(grid), dim3(ATT_THREADS), lds, st, a);
+  return GCT_OK;
+}
+template <int NDT, int NT>
+int launch_bwd(const AttnArgs& a, size_t lds, unsigned grid, hipStream_t st) {
+  int rc = ensure_lds(attn_bwd_kernel<NDT, NT>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((attn_bwd_kernel<NDT, NT>), dim3(grid), dim3(ATT_THREADS), lds, st, a);
+  return GCT_OK;
+}
+template <int NT>
+int launch_fwd_dk(int dk, const AttnArgs& a, size_t lds, unsigned grid, hipStream_t st) {
+  return dk == 64 ? launch_fwd<4, NT>(a, lds, grid, st) : dk == 32 ? launch_fwd<2, NT>(a, lds, grid, st)
+                                                                   : launch_fwd<1, NT>(a, lds, grid, st);
+}
+template <int NT>
+int launch_bwd_dk(int dk, const AttnArgs& a, size_t lds, unsigned grid, hipStream_t st) {
+  return dk == 64 ? launch_bwd<4, NT>(a, lds, grid, st) : dk == 32 ? launch_bwd<2, NT>(a, lds, grid, st)
+                                                                   : launch_bwd<1, NT>(a, lds, grid, st);
+}
 
 }  // namespace
 
+extern "C" int gct_attn_mask_pack(const uint8_t* mask, int64_t mask_sb, int64_t mask_sq, int B, int Lq, int Lk,
+                                  uint32_t* bits, void* stream) {
+  GCT_CHECK_ARG(mask && bits && B >= 0 && Lq > 0 && Lk > 0 && Lk <= 32 * MASK_W && gct_aligned16(bits),
+                "attn_mask_pack: bad args (Lk <= %d)", 32 * MASK_W);
+  const int rows = mask_sq == 0 ? 1 : Lq;           // key-padding mask: one row per batch
+  const int64_t n = (int64_t)B * rows * MASK_W;
+  if (n == 0) return GCT_OK;
+  hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask,
+                     mask_sb, mask_sq, B, rows, Lk, bits);
+  GCT_LAUNCH_CHECK("attn_mask_pack");
+  return GCT_OK;
+}
+
 extern "C" int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk,
-                            const float* v, int64_t ldv, const uint8_t* mask, int64_t mask_sb,
-                            int64_t mask_sq, float* o, int64_t ldo, float* lse, float* probs, int B,
+                            const float* v, int64_t ldv, const uint32_t* mbits, int64_t mb_sb,
+                            int64_t mb_sq, float* o, int64_t ldo, float* lse, float* probs, int B,
                             int H, int Lq, int Lk, int dk, float scale, float p, uint64_t seed,
                             uint32_t site, void* stream) {
-  int rc = check_common("attn_fwd", q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dk, p);
+  int rc = check_common("attn_fwd", q, ldq, k, ldk, v, ldv, mbits, mb_sb, mb_sq, B, H, Lq, Lk, dk, p);
   if (rc) return rc;
   GCT_CHECK_ARG(o && lse && ldo % 4 == 0 && gct_aligned16(o), "attn_fwd: bad output");
   if (B == 0) return GCT_OK;
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
-  a.mask = mask; a.mask_sb = mask_sb; a.mask_sq = mask_sq;
+  a.mbits = mbits; a.mb_sb = mb_sb; a.mb_sq = mb_sq;
   a.o = o; a.ldo = ldo; a.lse = lse; a.probs = probs;
-  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.npairs = B * H; a.scale = scale;
   a.thr = gct_drop_threshold(p); a.keep_scale = 1.0f / (1.0f - p); a.rng = gct_rng_make(seed, site);
   const int LQP = (Lq + 15) & ~15, LKP = (Lk + 15) & ~15, SD = dk + 4;
-  const size_t lds = (size_t)(2 * LKP) * SD * 4 + (size_t)LQP * LKP + MAPS_BYTES;
-  dim3 grid((unsigned)(B * H)), block(FWD_THREADS);
-  hipStream_t st = (hipStream_t)stream;
-  static bool f4 = false, f2 = false, f1 = false;
+  const int nt = (LQP > LKP ? LQP : LKP) / 16;
+  const size_t lds = (size_t)(2 * LKP) * SD * 4;
   GCT_CHECK_ARG(lds <= 160 * 1024, "attn_fwd: needs %zu B of LDS", lds);
-  if (dk == 64) { if ((rc = ensure_lds(attn_fwd_kernel<4>, lds, &f4))) return rc; hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, block, lds, st, a); }
-  else if (dk == 32) { if ((rc = ensure_lds(attn_fwd_kernel<2>, lds, &f2))) return rc; hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, lds, st, a); }
-  else { if ((rc = ensure_lds(attn_fwd_kernel<1>, lds, &f1))) return rc; hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, lds, st, a); }
+  // persistent workgroups: as many as are resident together (2 per CU at L <= 128, 1 beyond)
+  const int per_cu = lds <= 76 * 1024 ? 2 : 1;
+  const int64_t want = (int64_t)num_cus() * per_cu;
+  const unsigned grid = (unsigned)(a.npairs < want ? a.npairs : want);
+  hipStream_t st = (hipStream_t)stream;
+  rc = nt <= 6 ? launch_fwd_dk<6>(dk, a, lds, grid, st) : nt <= 8 ? launch_fwd_dk<8>(dk, a, lds, grid, st)
+                                                                  : launch_fwd_dk<13>(dk, a, lds, grid, st);
+  if (rc) return rc;
   GCT_LAUNCH_CHECK("attn_fwd");
   return GCT_OK;
 }
 
 extern "C" int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk,
-                            const float* v, int64_t ldv, const uint8_t* mask, int64_t mask_sb,
-                            int64_t mask_sq, const float* o, const float* dout, int64_t ldo,
-                            const float* lse, float* delta, float* dq, int64_t lddq, float* dk_,
+                            const float* v, int64_t ldv, const uint32_t* mbits, int64_t mb_sb,
+                            int64_t mb_sq, const float* o, const float* dout, int64_t ldo,
+                            const float* lse, float* dq, int64_t lddq, float* dk_,
                             int64_t lddk, float* dv, int64_t lddv, int B, int H, int Lq, int Lk,
                             int dk, float scale, float p, uint64_t seed, uint32_t site,
                             void* stream) {
-  (void)delta;
-  int rc = check_common("attn_bwd", q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, dk, p);
+  int rc = check_common("attn_bwd", q, ldq, k, ldk, v, ldv, mbits, mb_sb, mb_sq, B, H, Lq, Lk, dk, p);
   if (rc) return rc;
   GCT_CHECK_ARG(o && dout && lse && dq && dk_ && dv, "attn_bwd: null pointer");
   GCT_CHECK_ARG(ldo % 4 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 &&
@@ -650,21 +692,23 @@ extern "C" int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t
   if (B == 0) return GCT_OK;
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
-  a.mask = mask; a.mask_sb = mask_sb; a.mask_sq = mask_sq;
+  a.mbits = mbits; a.mb_sb = mb_sb; a.mb_sq = mb_sq;
   a.o_in = o; a.dout = dout; a.ldo = ldo; a.lse_in = lse;
   a.dq = dq; a.dk = dk_; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
-  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.npairs = B * H; a.scale = scale;
   a.thr = gct_drop_threshold(p); a.keep_scale = 1.0f / (1.0f - p); a.rng = gct_rng_make(seed, site);
   const int LQP = (Lq + 15) & ~15, LKP = (Lk + 15) & ~15, SD = dk + 4;
-  const size_t lds = (size_t)(2 * LQP + 2 * LKP) * SD * 4 + (size_t)LQP * 8 + (size_t)LQP * LKP +
-                     MAPS_BYTES;
-  dim3 grid((unsigned)(B * H)), block(BWD_THREADS);
-  hipStream_t st = (hipStream_t)stream;
-  static bool f4 = false, f2 = false, f1 = false;
+  const int LMX = LQP > LKP ? LQP : LKP, nt = LMX / 16;
+  const int MW = nt <= 6 ? 3 : nt <= 8 ? 4 : 7;
+  const size_t lds = (size_t)(2 * LMX) * SD * 4 + (size_t)LQP * 8 + (size_t)LQP * MW * 8 + (size_t)LQP * 2;
   GCT_CHECK_ARG(lds <= 160 * 1024, "attn_bwd: needs %zu B of LDS", lds);
-  if (dk == 64) { if ((rc = ensure_lds(attn_bwd_kernel<4>, lds, &f4))) return rc; hipLaunchKernelGGL(attn_bwd_kernel<4>, grid, block, lds, st, a); }
-  else if (dk == 32) { if ((rc = ensure_lds(attn_bwd_kernel<2>, lds, &f2))) return rc; hipLaunchKernelGGL(attn_bwd_kernel<2>, grid, block, lds, st, a); }
-  else { if ((rc = ensure_lds(attn_bwd_kernel<1>, lds, &f1))) return rc; hipLaunchKernelGGL(attn_bwd_kernel<1>, grid, block, lds, st, a); }
+  const int per_cu = lds <= 50 * 1024 ? 3 : lds <= 76 * 1024 ? 2 : 1;
+  const int64_t want = (int64_t)num_cus() * per_cu * 2;            // a few pairs per workgroup keep the tail short
+  const unsigned grid = (unsigned)(a.npairs < want ? a.npairs : want);
+  hipStream_t st = (hipStream_t)stream;
+  rc = nt <= 6 ? launch_bwd_dk<6>(dk, a, lds, grid, st) : nt <= 8 ? launch_bwd_dk<8>(dk, a, lds, grid, st)
+                                                                  : launch_bwd_dk<13>(dk, a, lds, grid, st);
+  if (rc) return rc;
   GCT_LAUNCH_CHECK("attn_bwd");
   return GCT_OK;
 }

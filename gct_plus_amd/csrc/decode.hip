@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
     const float* __restrict__ q, int64_t ldq, const float* __restrict__ k, const float* __restrict__ v,
     int64_t kv_row, int64_t kv_batch, const uint8_t* __restrict__ valid, int64_t valid_sb,
     float* __restrict__ o, int64_t ldo, int n, int H, int Lc, float scale) {
-  __shared__ float sc[4][128];
+  __shared__ float sc[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
   if (pair >= (int64_t)n * H) return;
@@ -142,7 +142,7 @@ extern "C" int gct_attn_decode(const float* q, int64_t ldq, const float* k, cons
                                int64_t kv_row, int64_t kv_batch, const uint8_t* valid,
                                int64_t valid_sb, float* o, int64_t ldo, int n, int H, int Lc, int dk,
                                float scale, void* stream) {
-  GCT_CHECK_ARG(q && k && v && o && n >= 0 && H > 0 && Lc > 0 && Lc <= 128, "attn_decode: bad args");
+  GCT_CHECK_ARG(q && k && v && o && n >= 0 && H > 0 && Lc > 0 && Lc <= 256, "attn_decode: bad args");
   GCT_CHECK_ARG(dk == 16 || dk == 32 || dk == 64, "attn_decode: head dim %d unsupported", dk);
   GCT_CHECK_ARG(ldq % 4 == 0 && kv_row % 4 == 0 && kv_batch % 4 == 0 && gct_aligned16(q) &&
                     gct_aligned16(k) && gct_aligned16(v),

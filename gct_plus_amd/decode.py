@@ -38,7 +38,7 @@ class KVDecoder:
 
     # -------------------------------------------------------------------------------------
     @torch.no_grad()
-    def start(self, z, src_mask, dconds=None, max_total_len=128):
+    def start(self, z, src_mask, dconds=None, max_total_len=208):
         """z [n, L_e, latent]; src_mask bool [n,1,L_e] (as the reference builds it)."""
         dec, d = self.dec, self.d
         dev = z.device
@@ -62,8 +62,8 @@ class KVDecoder:
             sv = torch.cat([torch.ones(n, nc, dtype=torch.uint8, device=dev), sv], dim=1)
         self.src_valid = sv.contiguous()
         self.n, self.Lk, self.T = n, Lk, int(max_total_len)
-        if self.T > 128 or Lk > 128:
-            raise ValueError("decode lengths above 128 are not supported by gct_attn_decode")
+        if self.T > 256 or Lk > 256:
+            raise ValueError("decode lengths above 256 are not supported by gct_attn_decode")
         self.cross_kv = []
         for layer in dec.layers:                                   # cross K/V: once per sequence
             kv = torch.empty(n * Lk, 2 * d, device=dev)

@@ -263,6 +263,7 @@ def encoder_trunk_fwd(enc, run: Run, src, mask_u8, econds, want_probs=False):
         cond = ops.small_linear_fwd(econds.contiguous(), enc.embed_cond2enc.weight,
                                     enc.embed_cond2enc.bias)
     L = S + nc
+    mask_u8 = ops.pack_mask(mask_u8, B, L, L)           # bits: once per call, shared by all layers / heads / backward
     site_pe = run.site()
     x = ops.embed_pe_fwd(src, enc.embed_sentence.embed.weight, cond, _pe2d(enc.pe, L), nc,
                          math.sqrt(d), run.p, run.seed, site_pe)
@@ -322,14 +323,16 @@ def decoder_trunk_fwd(dec, run: Run, trg, z, src_mask_u8, trg_mask_u8, dconds, w
             ones = torch.ones(B, nc, dtype=torch.uint8, device=src_mask_u8.device)
             src_mask_u8 = torch.cat([ones, src_mask_u8.view(B, Le)], dim=1).contiguous()
     lsv, p1s, p2s = [], [], []
+    src_m = ops.pack_mask(src_mask_u8, B, T, Lk)
+    trg_m = ops.pack_mask(trg_mask_u8, B, T, T)
     for layer in dec.layers:
-        x, sv, p1, p2 = dec_layer_fwd(run, layer, x, e, B, T, Lk, src_mask_u8, trg_mask_u8,
-                                      want_probs)
+        x, sv, p1, p2 = dec_layer_fwd(run, layer, x, e, B, T, Lk, src_m, trg_m, want_probs)
         lsv.append(sv)
         p1s.append(p1)
         p2s.append(p2)
     y, mean, rstd = ops.norm_fwd(x, dec.norm.alpha, dec.norm.bias, dec.norm.eps)
-    saved = (trg, z2, dconds, site_pe, lsv, x, mean, rstd, B, T, Le, Lk, c2d, c2l, trg_mask_u8)
+    saved = (trg, z2, dconds, site_pe, lsv, x, mean, rstd, B, T, Le, Lk, c2d, c2l,
+             trg_mask_u8.u8 if isinstance(trg_mask_u8, ops.MaskBits) else trg_mask_u8)
     return y.view(B, T, d), saved, p1s, p2s
 
 

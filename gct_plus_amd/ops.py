@@ -388,26 +388,57 @@ def dropout_bwd(dout2d, p, seed, site, out=None):
 
 
 # ------------------------------------------------------------------------------ attention
-def attn_fwd(q, k, v, ld_q, ld_k, ld_v, mask_u8, B, H, Lq, Lk, dk, p, seed, site, out=None,
+class MaskBits:
+    """An attention mask packed for the kernels (gct_attn_mask_pack): one bit per key, 8 words per query row.
+    Built once per trunk call from the reference's bool / int64 mask and shared by every layer, head and the
+    backward pass.  `u8` keeps the byte form (ops.LiveRows checks the decoder's zero-row shortcut against it)."""
+
+    def __init__(self, mask_u8, B, Lq, Lk):
+        _chk(mask_u8, "attn.mask", torch.uint8)
+        if Lk > 256 or Lq > 256:
+            raise _lib.GctError(f"attention: sequence length {max(Lq, Lk)} > 256 unsupported")
+        sb, sq = _mask_strides(mask_u8, B, Lq, Lk)
+        rows = 1 if sq == 0 else Lq
+        self.u8, self.B, self.Lq, self.Lk = mask_u8, B, Lq, Lk
+        self.bits = torch.empty(B, rows, 8, dtype=torch.int32, device=mask_u8.device)
+        self.sb, self.sq = rows * 8, (0 if sq == 0 else 8)
+        check(_L().gct_attn_mask_pack(_p(mask_u8), sb, sq, B, Lq, Lk, _p(self.bits), _st()), "gct_attn_mask_pack")
+
+
+def pack_mask(mask, B, Lq, Lk) -> Optional["MaskBits"]:
+    """None | MaskBits | uint8 / bool / int64 mask of [B,Lk], [B,1,Lk] or [B,Lq,Lk] elements -> MaskBits."""
+    if mask is None or isinstance(mask, MaskBits):
+        if isinstance(mask, MaskBits) and (mask.B, mask.Lk) != (B, Lk):
+            raise _lib.GctError(f"packed mask was built for B={mask.B}, Lk={mask.Lk}, not B={B}, Lk={Lk}")
+        return mask
+    return MaskBits(to_mask_u8(mask), B, Lq, Lk)
+
+
+def _mb(mask, B, Lq, Lk):
+    mb = pack_mask(mask, B, Lq, Lk)
+    return (None, 0, 0) if mb is None else (mb.bits.data_ptr(), mb.sb, mb.sq)
+
+
+def attn_fwd(q, k, v, ld_q, ld_k, ld_v, mask, B, H, Lq, Lk, dk, p, seed, site, out=None,
              want_probs=False):
     """q/k/v: tensors whose data_ptr is element (b=0,l=0,h=0,0) with row strides ld_*.
-    mask_u8: None | [B,Lk] / [B,1,Lk] (key padding) | [B,Lq,Lk]."""
+    mask: None | MaskBits | uint8 [B,Lk] / [B,1,Lk] (key padding) / [B,Lq,Lk] (packed on the fly)."""
     dev = q.device
     o = torch.empty(B * Lq, H * dk, dtype=torch.float32, device=dev) if out is None else out
     lse = torch.empty(B * H * Lq, dtype=torch.float32, device=dev)
     probs = torch.empty(B, H, Lq, Lk, dtype=torch.float32, device=dev) if want_probs else None
-    sb, sq = _mask_strides(mask_u8, B, Lq, Lk)
-    check(_L().gct_attn_fwd(_p(q), ld_q, _p(k), ld_k, _p(v), ld_v, _p(mask_u8), sb, sq, _p(o),
+    mp, sb, sq = _mb(mask, B, Lq, Lk)
+    check(_L().gct_attn_fwd(_p(q), ld_q, _p(k), ld_k, _p(v), ld_v, mp, sb, sq, _p(o),
                             o.stride(0), _p(lse), _p(probs), B, H, Lq, Lk, dk,
                             1.0 / math.sqrt(dk), p, seed, site, _st()), "gct_attn_fwd")
     return o, lse, probs
 
 
-def attn_bwd(q, k, v, ld_q, ld_k, ld_v, mask_u8, o, dout, lse, dq, dk_, dv, ld_dq, ld_dk, ld_dv,
+def attn_bwd(q, k, v, ld_q, ld_k, ld_v, mask, o, dout, lse, dq, dk_, dv, ld_dq, ld_dk, ld_dv,
              B, H, Lq, Lk, dk, p, seed, site):
-    sb, sq = _mask_strides(mask_u8, B, Lq, Lk)
-    check(_L().gct_attn_bwd(_p(q), ld_q, _p(k), ld_k, _p(v), ld_v, _p(mask_u8), sb, sq, _p(o),
-                            _p(dout), o.stride(0), _p(lse), None, _p(dq), ld_dq, _p(dk_), ld_dk,
+    mp, sb, sq = _mb(mask, B, Lq, Lk)
+    check(_L().gct_attn_bwd(_p(q), ld_q, _p(k), ld_k, _p(v), ld_v, mp, sb, sq, _p(o),
+                            _p(dout), o.stride(0), _p(lse), _p(dq), ld_dq, _p(dk_), ld_dk,
                             _p(dv), ld_dv, B, H, Lq, Lk, dk, 1.0 / math.sqrt(dk), p, seed, site,
                             _st()), "gct_attn_bwd")
 

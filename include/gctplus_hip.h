@@ -207,19 +207,25 @@ int gct_dropout_bwd(const float* dout, float* dy, int64_t rows, int cols, float 
 /* Model/sublayers.py:29-41 attention() + head split/merge :64-69.
  * q,k,v are [B][L][H*dk]-shaped views with leading dimension ld* (so the fused QKV
  * buffer is consumed in place); head h uses columns h*dk..h*dk+dk-1.
- * mask: uint8, element (b,q,k) at mask[b*mask_sb + q*mask_sq + k]; 0 => score := -1e9
- * (masked_fill semantics; mask_sq == 0 broadcasts a key-padding mask). nullable.
+ * mask: PACKED by gct_attn_mask_pack -- one bit per key, 8 uint32 words per query row (Lk <= 256), bit (k & 31)
+ * of word k >> 5 set <=> key k visible; row of (b,q) at mbits + b*mb_sb + q*mb_sq (strides in words, multiples of
+ * 4; mb_sq == 0 broadcasts a key-padding mask); a cleared bit => score := -1e9 (masked_fill semantics). nullable.
+ * Pack once per forward: the same rows serve every layer, every head and the backward pass.
  * o: [B][Lq][H*dk] (heads merged, ready for the out projection); lse: [B][H][Lq].
  * probs (nullable): pre-dropout probabilities [B][H][Lq][Lk] (get_attn path).
- * dk % 4 == 0, dk <= 64, Lq,Lk <= 128. */
+ * dk in {16, 32, 64}; Lq, Lk <= 256 (the reference's positional table ends at 200: Model/modules.py:117). */
+/* mask: uint8, element (b,q,k) at mask[b*mask_sb + q*mask_sq + k] (0 = masked); mask_sq == 0: key-padding mask
+ * [B][Lk] -> bits [B][8]; else bits [B][Lq][8]. */
+int gct_attn_mask_pack(const uint8_t* mask, int64_t mask_sb, int64_t mask_sq, int B, int Lq, int Lk,
+                       uint32_t* bits, void* stream);
 int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
-                 int64_t ldv, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
+                 int64_t ldv, const uint32_t* mbits, int64_t mb_sb, int64_t mb_sq,
                  float* o, int64_t ldo, float* lse, float* probs, int B, int H, int Lq, int Lk,
                  int dk, float scale, float p, uint64_t seed, uint32_t site, void* stream);
-/* dq/dk/dv written (overwrite) with the same layout as q/k/v. delta: scratch [B][H][Lq]. */
+/* dq/dk/dv written (overwrite) with the same layout as q/k/v. */
 int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
-                 int64_t ldv, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
-                 const float* o, const float* dout, int64_t ldo, const float* lse, float* delta,
+                 int64_t ldv, const uint32_t* mbits, int64_t mb_sb, int64_t mb_sq,
+                 const float* o, const float* dout, int64_t ldo, const float* lse,
                  float* dq, int64_t lddq, float* dk_, int64_t lddk, float* dv, int64_t lddv,
                  int B, int H, int Lq, int Lk, int dk, float scale, float p, uint64_t seed,
                  uint32_t site, void* stream);
@@ -264,7 +270,7 @@ int gct_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
  * two kernels (with the GEMM/norm/embedding entry points above) make one step a fixed chain.
  * gct_attn_decode: ONE query row per (sample, head): q [n][H*dk] (ld ldq); keys/values row j of
  * sample b at k + b*kv_batch + j*kv_row (+ h*dk); valid (nullable) uint8 [n][>=Lc], 0 => -1e9;
- * o [n][H*dk].  Lc <= 128. */
+ * o [n][H*dk].  Lc <= 256. */
 int gct_attn_decode(const float* q, int64_t ldq, const float* k, const float* v, int64_t kv_row,
                     int64_t kv_batch, const uint8_t* valid, int64_t valid_sb, float* o, int64_t ldo,
                     int n, int H, int Lc, int dk, float scale, void* stream);

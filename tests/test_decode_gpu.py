@@ -122,3 +122,25 @@ def test_sampling_front_end_all_model_types():
         if mtype == "vaetf":
             zz, mu, lv = sp.encode_smiles(SMILES[:3])
             assert mu.shape[0] == 3 and mu.shape[2] == 16
+
+
+def test_kv_decode_long_scaffold_prefix():
+    """Caches and cross-attention keys beyond 128 positions (a long scaffold prefix + a 150-row latent): the cached
+    path equals the un-cached reference-style loop token for token (attention kernels and gct_attn_decode cover the
+    reference's whole positional table, Model/modules.py:117)."""
+    from gct_plus_amd.decode import KVDecoder, reference_style_decode
+    mtype = "pscavaetf"
+    model = build(mtype)
+    n, Le = 5, 150 + 3
+    g = torch.Generator().manual_seed(23)
+    z = torch.randn(n, Le, TINY["latent_dim"], generator=g).cuda()
+    dconds = torch.randn(n, 3, generator=g).cuda()
+    lens = torch.randint(100, Le + 1, (n,), generator=g)
+    src_mask = (torch.arange(Le)[None, :] < lens[:, None]).unsqueeze(1).cuda()
+    pre = torch.randint(5, 30, (n, 118), generator=g)
+    ys0 = torch.cat([torch.full((n, 1), synthetic.SOS_ID), pre, torch.full((n, 1), 4)], 1).cuda()      # 120 tokens
+    ref = reference_style_decode(model, z, src_mask, dconds, ys0, synthetic.PAD_ID, -1, 50)
+    kd = KVDecoder(model, synthetic.PAD_ID, synthetic.SOS_ID, -1)
+    kd.start(z, src_mask, dconds, max_total_len=176)
+    ys = kd.generate(ys0, max_strlen=50)
+    assert ys.shape[1] == 169 and torch.equal(ys, ref)

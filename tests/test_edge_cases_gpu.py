@@ -73,17 +73,32 @@ def test_odd_shapes(mtype, B, S):
     compare(mtype, m, cfg, P, ds)
 
 
-def test_maximum_length_and_beyond():
-    """L_k = 128 is the kernels' limit (the reference's PE table allows 200, its data never exceeds
-    ~86): n_c + S = 3 + 122 = 125 encoder rows, cross keys 128, decoder 123."""
+@pytest.mark.parametrize("mtype,B,S", [("scavaetf", 3, 170), ("pvaetf", 2, 197), ("vaetf", 2, 127)])
+def test_long_sequences_vs_oracle(mtype, B, S):
+    """The reference's positional table admits any L <= 200 (Model/modules.py:117); scaffold + <sep> + SMILES rows
+    reach ~170 (SURVEY 5).  L_e = 170 / T = 171; n_c + S = 3 + 197 = 200 encoder rows, 203 cross keys, T = 198;
+    and 127 / 128 (the boundary between the 8-tile and the 13-tile attention kernels).  Ragged lengths."""
+    m, cfg, P = make(mtype, TINY)
+    ds = synthetic.make_dataset(B, S, mtype, seed=S)
+    for i in range(1, B):
+        ln = S - 40 * i
+        ds["src"][i, ln:] = PAD
+        ds["trg"][i, ln + 1] = synthetic.EOS_ID
+        ds["trg"][i, ln + 2:] = PAD
+    compare(mtype, m, cfg, P, ds)
+
+
+def test_beyond_the_positional_table():
+    """Past 200 positions the reference cannot run either (its pe buffer has 200 rows): loud error, as before."""
     m, cfg, P = make("pvaetf", TINY)
-    ds = synthetic.make_dataset(2, 122, "pvaetf", seed=1, fixed_len=True)
-    compare("pvaetf", m, cfg, P, ds)
-    from gct_plus_amd import _lib
     from gct_plus_amd.Model import forward_propagation
-    big = {k: v.cuda() for k, v in synthetic.make_dataset(2, 130, "pvaetf", seed=1).items()}
-    with pytest.raises(_lib.GctError, match="sequence length"):
+    big = {k: v.cuda() for k, v in synthetic.make_dataset(2, 198, "pvaetf", seed=1).items()}      # 3 + 198 = 201
+    with pytest.raises(ValueError, match="positional table"):
         forward_propagation["pvaetf"](m, big, PAD, False)
+    from gct_plus_amd import _lib, ops
+    x = torch.zeros(2 * 209, 64, device="cuda")
+    with pytest.raises(_lib.GctError, match="sequence length"):
+        ops.attn_fwd(x, x, x, 64, 64, 64, None, 2, 4, 209, 209, 16, 0.0, 0, 0)
 
 
 def test_non_variational():

@@ -159,7 +159,10 @@ def ref_attention(q, k, v, mask, scale, keep=None, pkeep=1.0):
 
 @pytest.mark.parametrize("B,H,Lq,Lk,dk,mode", [(3, 4, 20, 20, 16, "pad"), (2, 8, 81, 81, 64, "causal"),
                                                (2, 8, 81, 86, 64, "pad"), (2, 2, 5, 128, 32, "none"),
-                                               (1, 8, 80, 80, 64, "pad")])
+                                               (1, 8, 80, 80, 64, "pad"), (3, 2, 97, 120, 16, "pad"),
+                                               (2, 8, 171, 171, 64, "causal"), (2, 8, 171, 173, 64, "pad"),
+                                               (1, 4, 200, 200, 64, "causal"), (2, 2, 5, 208, 32, "none"),
+                                               (2, 4, 203, 198, 16, "pad")])
 def test_attention(ops, B, H, Lq, Lk, dk, mode):
     d = H * dk
     qkv = rnd(B * max(Lq, Lk), 3 * d, seed=1)
@@ -196,18 +199,51 @@ def test_attention(ops, B, H, Lq, Lk, dk, mode):
     close(dkv[:, d:].reshape(B, Lk, H, dk).transpose(1, 2), vd.grad, 2e-5, 1e-4, "dv")
 
 
-def test_attention_dropout(ops):
-    """V = identity recovers the dropped probabilities => the mask; the backward must use it."""
-    B, H, L, dk, p, seed = 2, 2, 48, 64, 0.25, 99
+def test_attention_many_pairs_per_workgroup(ops):
+    """More (batch, head) pairs than persistent workgroups (2 per CU): every workgroup walks several pairs through
+    the software pipeline (next pair's K / V / Q rows loaded during this pair's MFMAs).  Causal + ragged mask,
+    dropout off; forward and backward against fp64."""
+    B, H, L, dk = 96, 8, 81, 64                      # 768 pairs > 512 workgroups
+    d = H * dk
+    qkv = rnd(B * L, 3 * d, seed=11)
+    lens = torch.tensor([L - (i * 7) % 60 for i in range(B)])
+    pad = torch.arange(L)[None, :] < lens[:, None]
+    mask = (pad[:, None, :] & torch.tril(torch.ones(L, L, dtype=torch.bool))[None]).to(torch.uint8)
+    g = qkv.to(DEV)
+    o, lse, _ = ops.attn_fwd(g, g[:, d:], g[:, 2 * d:], 3 * d, 3 * d, 3 * d, mask.to(DEV), B, H, L, L, dk, 0.0, 0, 0)
+    sp = lambda t: t.double().reshape(B, L, H, dk).transpose(1, 2).requires_grad_()               # noqa: E731
+    qd, kd, vd = sp(qkv[:, :d]), sp(qkv[:, d:2 * d]), sp(qkv[:, 2 * d:])
+    oref, _ = ref_attention(qd, kd, vd, mask[:, None], 1 / math.sqrt(dk))
+    close(o.view(B, L, H, dk).transpose(1, 2), oref, 1e-5, 1e-5, "attn out (many pairs)")
+    do = rnd(B * L, d, seed=12)
+    do[40 * L:] = 0.0                                # whole samples without gradient: zero-dO tiles are skipped
+    oref.backward(do.double().view(B, L, H, dk).transpose(1, 2))
+    dqkv = torch.empty(B * L, 3 * d, device=DEV)
+    ops.attn_bwd(g, g[:, d:], g[:, 2 * d:], 3 * d, 3 * d, 3 * d, mask.to(DEV), o, do.to(DEV), lse, dqkv, dqkv[:, d:],
+                 dqkv[:, 2 * d:], 3 * d, 3 * d, 3 * d, B, H, L, L, dk, 0.0, 0, 0)
+    un = lambda t: t.reshape(B, L, H, dk).transpose(1, 2)                                            # noqa: E731
+    close(un(dqkv[:, :d]), qd.grad, 2e-5, 1e-4, "dq (many pairs)")
+    close(un(dqkv[:, d:2 * d]), kd.grad, 2e-5, 1e-4, "dk (many pairs)")
+    close(un(dqkv[:, 2 * d:]), vd.grad, 2e-5, 1e-4, "dv (many pairs)")
+
+
+@pytest.mark.parametrize("L", [48, 170])
+def test_attention_dropout(ops, L):
+    """One-hot V blocks recover the dropped probabilities => the keep mask the FORWARD used (64 keys per run, same
+    seed); the backward must regenerate exactly that mask (both of its phases)."""
+    B, H, dk, p, seed = 2, 2, 64, 0.25, 99
     d = H * dk
     q, k = rnd(B * L, d, seed=1), rnd(B * L, d, seed=2)
-    eye = torch.zeros(B, L, H, dk)
-    for i in range(L):
-        eye[:, i, :, i] = 1.0
-    v = eye.view(B * L, d)
-    qg, kg, vg = q.to(DEV), k.to(DEV), v.to(DEV)
-    o, lse, probs = ops.attn_fwd(qg, kg, vg, d, d, d, None, B, H, L, L, dk, p, seed, 3, want_probs=True)
-    pd = o.view(B, L, H, dk).transpose(1, 2)[..., :L].cpu()          # [B,H,L,L] dropped probs
+    qg, kg = q.to(DEV), k.to(DEV)
+    pd = torch.zeros(B, H, L, L)
+    for k0 in range(0, L, dk):
+        eye = torch.zeros(B, L, H, dk)
+        for i in range(k0, min(L, k0 + dk)):
+            eye[:, i, :, i - k0] = 1.0
+        o, lse, probs = ops.attn_fwd(qg, kg, eye.view(B * L, d).to(DEV), d, d, d, None, B, H, L, L, dk, p, seed, 3,
+                                     want_probs=True)
+        n = min(L, k0 + dk) - k0
+        pd[..., k0:k0 + n] = o.view(B, L, H, dk).transpose(1, 2)[..., :n].cpu()     # [B,H,L,keys k0..] dropped probs
     pr = probs.cpu()
     keep = pd != 0
     assert abs(keep.float().mean().item() - (1 - p)) < 0.02
