@@ -65,8 +65,11 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// Staging of a [B][L][ld] head slice into LDS [LP][SD] (zero padded, optional scale) is split in a load half
-// (registers) and a store half, so the loads of the NEXT pair can be in flight during the MFMAs of this one.
+// Staging of a [B][L][ld] head slice into LDS [LP][SD] (zero padded) is split in a load half (registers) and a
+// store half, so the loads of the NEXT pair can be in flight during the MFMAs of this one.  The load half is
+// branch-free and does not touch the loaded values (rows beyond L re-read row L-1; they are zeroed by the store
+// half): anything that consumes a loaded register makes the wave wait for it AND for every older load (vmcnt is
+// in-order), which would turn the prefetch into a stall.
 template <int DK, int NT>
 struct Stage {
   static constexpr int SD = DK + 4, C = DK / 4;
@@ -77,20 +80,17 @@ struct Stage {
     for (int it = 0; it < ITERS; ++it) {
       const int idx = tid + it * ATT_THREADS;
       const int r = idx / C, c = idx - r * C;
-      v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < L) v[it] = *reinterpret_cast<const float4*>(src + ((int64_t)b * L + r) * ld + h * DK + c * 4);
+      const int rr = r < L ? r : L - 1;
+      v[it] = *reinterpret_cast<const float4*>(src + ((int64_t)b * L + rr) * ld + h * DK + c * 4);
     }
   }
-  __device__ __forceinline__ void store(float* dst, int LP, float scale, int tid) const {
+  __device__ __forceinline__ void store(float* dst, int L, int LP, int tid) const {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int idx = tid + it * ATT_THREADS;
       const int r = idx / C, c = idx - r * C;
-      if (r < LP) {
-        float4 w = v[it];
-        w.x *= scale; w.y *= scale; w.z *= scale; w.w *= scale;
-        *reinterpret_cast<float4*>(dst + r * SD + c * 4) = w;
-      }
+      if (r < LP)
+        *reinterpret_cast<float4*>(dst + r * SD + c * 4) = r < L ? v[it] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 };
@@ -106,18 +106,16 @@ __device__ __forceinline__ void row_frag(float4 (&f)[NDT], const float* lds, int
   for (int j = 0; j < NDT; ++j)
     f[j] = *reinterpret_cast<const float4*>(lds + row * SD + g * 4 * NDT + 4 * j);
 }
-// the same fragment straight from global memory (row of a [B][L][ld] head slice), zero beyond L
+// The same fragment straight from global memory (row of a [B][L][ld] head slice).  Rows beyond L re-read row
+// L-1 (finite values; every consumer discards or masks what such rows produce) -- no select on the loaded data,
+// see Stage.
 template <int NDT>
 __device__ __forceinline__ void row_frag_global(float4 (&f)[NDT], const float* src, int64_t ld, int b, int h, int L,
-                                                int row, int g, float scale) {
+                                                int row, int g) {
+  const int rr = row < L ? row : L - 1;
+  const float* p = src + ((int64_t)b * L + rr) * ld + h * 16 * NDT + g * 4 * NDT;
 #pragma unroll
-  for (int j = 0; j < NDT; ++j) {
-    f[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < L) {
-      f[j] = *reinterpret_cast<const float4*>(src + ((int64_t)b * L + row) * ld + h * 16 * NDT + g * 4 * NDT + 4 * j);
-      f[j].x *= scale; f[j].y *= scale; f[j].z *= scale; f[j].w *= scale;
-    }
-  }
+  for (int j = 0; j < NDT; ++j) f[j] = *reinterpret_cast<const float4*>(p + 4 * j);
 }
 template <int NDT>
 __device__ __forceinline__ f32x4 dot_frag(const float4 (&a)[NDT], const float4 (&b)[NDT], f32x4 acc) {
@@ -137,21 +135,25 @@ __device__ __forceinline__ uint32_t range_word(int w, int Lk) {
   return n >= 32 ? 0xffffffffu : (n > 0 ? ((1u << n) - 1u) : 0u);
 }
 
-// packed mask words of query row q (all ones without a mask or beyond Lq)
+// packed mask words of query row q as stored (rows beyond Lq re-read row Lq-1); call only with a.mbits != null
 template <int MW>
-__device__ __forceinline__ void mask_row(uint32_t (&mw)[MW], const AttnArgs& a, int b, int q) {
+__device__ __forceinline__ void mask_row_raw(uint4 (&raw)[(MW + 3) / 4], const AttnArgs& a, int b, int q) {
+  const int qq = q < a.Lq ? q : a.Lq - 1;
+  const uint4* p = reinterpret_cast<const uint4*>(a.mbits + (int64_t)b * a.mb_sb + (int64_t)qq * a.mb_sq);
 #pragma unroll
-  for (int w = 0; w < MW; ++w) mw[w] = 0xffffffffu;
-  if (a.mbits && q < a.Lq) {
-    const uint4* p = reinterpret_cast<const uint4*>(a.mbits + (int64_t)b * a.mb_sb + (int64_t)q * a.mb_sq);
+  for (int w4 = 0; w4 < (MW + 3) / 4; ++w4) raw[w4] = p[w4];
+}
+// ... and their use: all ones without a mask or beyond Lq
+template <int MW>
+__device__ __forceinline__ void mask_row_use(uint32_t (&mw)[MW], const uint4 (&raw)[(MW + 3) / 4], const AttnArgs& a,
+                                             int q) {
+  const bool on = a.mbits && q < a.Lq;
 #pragma unroll
-    for (int w4 = 0; w4 < (MW + 3) / 4; ++w4) {
-      const uint4 x = p[w4];
-      if (4 * w4 + 0 < MW) mw[4 * w4 + 0] = x.x;
-      if (4 * w4 + 1 < MW) mw[4 * w4 + 1] = x.y;
-      if (4 * w4 + 2 < MW) mw[4 * w4 + 2] = x.z;
-      if (4 * w4 + 3 < MW) mw[4 * w4 + 3] = x.w;
-    }
+  for (int w4 = 0; w4 < (MW + 3) / 4; ++w4) {
+    if (4 * w4 + 0 < MW) mw[4 * w4 + 0] = on ? raw[w4].x : 0xffffffffu;
+    if (4 * w4 + 1 < MW) mw[4 * w4 + 1] = on ? raw[w4].y : 0xffffffffu;
+    if (4 * w4 + 2 < MW) mw[4 * w4 + 2] = on ? raw[w4].z : 0xffffffffu;
+    if (4 * w4 + 3 < MW) mw[4 * w4 + 3] = on ? raw[w4].w : 0xffffffffu;
   }
 }
 
@@ -173,25 +175,29 @@ __device__ __forceinline__ uint32_t tiles_for_q(const uint32_t (&mw)[MW], int q,
   return __builtin_amdgcn_readfirstlane(use);
 }
 
-__device__ __forceinline__ float score_of(float s, bool in_range, bool visible) {
-  return in_range ? (visible ? s : -1e9f) : -INFINITY;
+__device__ __forceinline__ float score_of(float s, bool in_range, bool visible, float masked = -1e9f) {
+  return in_range ? (visible ? s : masked) : -INFINITY;
 }
 
 // ------------------------------------------------------------------------------ forward
-// One query tile (16 rows) of one pair: S^T, softmax, P.V.  bq = this lane's (pre-scaled) Q fragment.
+// One query tile (16 rows) of one pair: S^T, softmax, P.V.  bq = this lane's RAW Q fragment (the 1/sqrt(dk) is
+// applied to the scores, after the product, like the reference's `matmul(q, k^T) / sqrt(d_k)`); mw = the packed
+// mask words of this lane's query row.
 template <int NDT, int NT, typename AfterS>
 __device__ __forceinline__ void fwd_unit(const AttnArgs& a, int b, int h, int u, float4 (&bq)[NDT],
-                                         const float* Ks, const float* Vs, int nkt, int lane, AfterS after_s) {
+                                         const uint32_t (&mw)[(NT + 1) / 2], const float* Ks, const float* Vs, int nkt,
+                                         int lane, AfterS after_s) {
   constexpr int DK = 16 * NDT, SD = DK + 4, MW = (NT + 1) / 2;
   const int g = lane >> 4, c16 = lane & 15;
   const int q = 16 * u + c16;
-  uint32_t mw[MW];
-  mask_row<MW>(mw, a, b, q);
   const uint32_t use = tiles_for_q<MW>(mw, q, a.Lq, a.Lk, nkt);
+  uint32_t rowvis = 0;
+#pragma unroll
+  for (int w = 0; w < MW; ++w) rowvis |= mw[w] & range_word(w, a.Lk);
   f32x4 sacc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // S^T[k][q] = sum_d K[k][d] * Qs[q][d]
+  // S^T[k][q] = sum_d K[k][d] * Q[q][d]
 #pragma unroll
   for (int t = 0; t < NT; ++t)
     if ((use >> t) & 1u) {
@@ -200,7 +206,7 @@ __device__ __forceinline__ void fwd_unit(const AttnArgs& a, int b, int h, int u,
       sacc[t] = dot_frag<NDT>(ak, bq, sacc[t]);
     }
   after_s();          // bq is dead from here on: the caller may reload it (next pair's rows)
-  // mask + softmax over keys (regs x tiles in-lane, then lanes l^16, l^32)
+  // scale + mask + softmax over keys (regs x tiles in-lane, then lanes l^16, l^32)
   float m = -INFINITY;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -208,7 +214,7 @@ __device__ __forceinline__ void fwd_unit(const AttnArgs& a, int b, int h, int u,
       const uint32_t nib = mw[t >> 1] >> ((t & 1) * 16 + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float sv = score_of(sacc[t][r], 16 * t + 4 * g + r < a.Lk, (nib >> r) & 1u);
+        const float sv = score_of(sacc[t][r] * a.scale, 16 * t + 4 * g + r < a.Lk, (nib >> r) & 1u);
         sacc[t][r] = sv;
         m = fmaxf(m, sv);
       }
@@ -231,7 +237,9 @@ __device__ __forceinline__ void fwd_unit(const AttnArgs& a, int b, int h, int u,
   l += __shfl_xor(l, 32, 64);
   const float inv = l > 0.f ? 1.0f / l : 0.f;
   const int64_t grow = ((int64_t)b * a.H + h) * a.Lq + q;
-  if (g == 0 && q < a.Lq) a.lse[grow] = m + __logf(l);
+  // A row without a visible key is uniform over its Lk keys (every score -1e9).  -1e9 + log(Lk) is not
+  // representable in fp32, so such a row stores log(Lk) and the backward scores its masked keys as 0, not -1e9.
+  if (g == 0 && q < a.Lq) a.lse[grow] = (rowvis ? m : 0.f) + __logf(l);
 #pragma unroll
   for (int t = 0; t < NT; ++t)
     if (t < nkt) {
@@ -270,7 +278,7 @@ __device__ __forceinline__ void fwd_unit(const AttnArgs& a, int b, int h, int u,
 
 template <int NDT, int NT, bool PIPE>
 __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_fwd_kernel(const AttnArgs a) {
-  constexpr int DK = 16 * NDT, SD = DK + 4, NW = ATT_THREADS / 64;
+  constexpr int DK = 16 * NDT, SD = DK + 4, NW = ATT_THREADS / 64, MW = (NT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
   const int LQP = (a.Lq + 15) & ~15, LKP = (a.Lk + 15) & ~15, nkt = LKP / 16, nqt = LQP / 16;
@@ -280,39 +288,52 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_fwd_kerne
   if (pair >= a.npairs) return;
   Stage<DK, NT> sk, sv;
   float4 bq[NDT];
+  uint4 mraw[(MW + 3) / 4] = {};
   {
     const int b = pair / a.H, h = pair - b * a.H;
     sk.load(a.k, a.ldk, b, h, a.Lk, tid);
     sv.load(a.v, a.ldv, b, h, a.Lk, tid);
-    row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, 16 * wave + c16, g, a.scale);
+    row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, 16 * wave + c16, g);
+    if (a.mbits) mask_row_raw<MW>(mraw, a, b, 16 * wave + c16);
   }
   for (;;) {
     const int b = pair / a.H, h = pair - b * a.H;
-    sk.store(Ks, LKP, 1.0f, tid);
-    sv.store(Vs, LKP, 1.0f, tid);
+    sk.store(Ks, a.Lk, LKP, tid);
+    sv.store(Vs, a.Lk, LKP, tid);
+    uint32_t mw[MW];
+    mask_row_use<MW>(mw, mraw, a, 16 * wave + c16);
     __syncthreads();
     const int next = pair + (int)gridDim.x;
     const bool more = next < a.npairs;
-    const int nb = more ? next / a.H : 0, nh = more ? next - nb * a.H : 0;
-    if (PIPE && more) {                  // next pair's K and V: in flight during the MFMAs below
+    const int nb = more ? next / a.H : b, nh = more ? next - nb * a.H : h;
+    // Next pair's operands: requested now, consumed at the top of the next iteration.  NOTHING loaded below this
+    // point may be consumed before then (a wait on a younger load waits for these too).
+    if (PIPE && more) {
       sk.load(a.k, a.ldk, nb, nh, a.Lk, tid);
       sv.load(a.v, a.ldv, nb, nh, a.Lk, tid);
+      if (a.mbits) mask_row_raw<MW>(mraw, a, nb, 16 * wave + c16);
     }
     for (int u = wave; u < nqt; u += NW) {
-      if (u != wave) row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, 16 * u + c16, g, a.scale);
+      if (u != wave) {                   // only when there are more query tiles than waves (L > 96)
+        row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, 16 * u + c16, g);
+        uint4 r2[(MW + 3) / 4] = {};
+        if (a.mbits) mask_row_raw<MW>(r2, a, b, 16 * u + c16);
+        mask_row_use<MW>(mw, r2, a, 16 * u + c16);
+      }
       const bool last = u + NW >= nqt;
-      fwd_unit<NDT, NT>(a, b, h, u, bq, Ks, Vs, nkt, lane, [&]() {
+      fwd_unit<NDT, NT>(a, b, h, u, bq, mw, Ks, Vs, nkt, lane, [&]() {
         // S^T was bq's last use: this wave's Q rows of the next pair arrive during softmax and P.V
-        if (PIPE && more && last) row_frag_global<NDT>(bq, a.q, a.ldq, nb, nh, a.Lq, 16 * wave + c16, g, a.scale);
+        if (PIPE && more && last) row_frag_global<NDT>(bq, a.q, a.ldq, nb, nh, a.Lq, 16 * wave + c16, g);
       });
     }
-    if (PIPE && more && wave >= nqt) row_frag_global<NDT>(bq, a.q, a.ldq, nb, nh, a.Lq, 16 * wave + c16, g, a.scale);
-    if (next >= a.npairs) break;
+    if (PIPE && more && wave >= nqt) row_frag_global<NDT>(bq, a.q, a.ldq, nb, nh, a.Lq, 16 * wave + c16, g);
+    if (!more) break;
     __syncthreads();                     // every wave is done reading Ks / Vs
     if (!PIPE) {
       sk.load(a.k, a.ldk, nb, nh, a.Lk, tid);
       sv.load(a.v, a.ldv, nb, nh, a.Lk, tid);
-      row_frag_global<NDT>(bq, a.q, a.ldq, nb, nh, a.Lq, 16 * wave + c16, g, a.scale);
+      row_frag_global<NDT>(bq, a.q, a.ldq, nb, nh, a.Lq, 16 * wave + c16, g);
+      if (a.mbits) mask_row_raw<MW>(mraw, a, nb, 16 * wave + c16);
     }
     pair = next;
   }
@@ -326,27 +347,38 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
   const int LQP = (a.Lq + 15) & ~15, LKP = (a.Lk + 15) & ~15, nkt = LKP / 16, nqt = LQP / 16;
   const int LMX = LQP > LKP ? LQP : LKP;
-  // region 0 holds {K, V} in phase A and {Q (scaled), dO} in phase B
+  // region 0 holds {K, V} in phase A and {Q, dO} in phase B
   float* R0 = smem;
   float* R1 = R0 + LMX * SD;
   float* lse_s = R1 + LMX * SD;                                   // [LQP]
   float* del_s = lse_s + LQP;                                     // [LQP]
   uint32_t* mb_s = reinterpret_cast<uint32_t*>(del_s + LQP);      // [LQP][MW] packed mask rows
-  uint32_t* kp_s = mb_s + LQP * MW;                               // [LQP][MW] dropout keep bits
+  uint32_t* kp_s = mb_s + LQP * MW;                               // [LQP][MW] dropout keep bits (written by phase A)
+  uint16_t* kp_h = reinterpret_cast<uint16_t*>(kp_s);             //   ... as one 16-bit half-word per (q, key tile)
   uint8_t* rowok = reinterpret_cast<uint8_t*>(kp_s + LQP * MW);   // [LQP] row sees a key (or is padding)
   uint8_t* rowlive = rowok + LQP;                                 // [LQP] dO row has a non-zero element
   for (int pair = blockIdx.x; pair < a.npairs; pair += (int)gridDim.x) {
     const int b = pair / a.H, h = pair - b * a.H;
     const int64_t lrow0 = ((int64_t)b * a.H + h) * a.Lq;
     // ---------------------------------------------------------------- phase A: K, V in LDS -> dQ
+    // every global load of this phase is issued up front: this wave's Q / dO / O rows and lse ride along with the
+    // K / V staging loads, so the MFMAs below start with everything on chip
+    const int q0 = 16 * wave + c16;
+    float4 bq[NDT], bd[NDT], bo[NDT];
+    row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, q0, g);
+    row_frag_global<NDT>(bd, a.dout, a.ldo, b, h, a.Lq, q0, g);
+    row_frag_global<NDT>(bo, a.o_in, a.ldo, b, h, a.Lq, q0, g);
+    float lse0 = a.lse_in[lrow0 + (q0 < a.Lq ? q0 : a.Lq - 1)];
     {
       Stage<DK, NT> sk, sv;
       sk.load(a.k, a.ldk, b, h, a.Lk, tid);
       sv.load(a.v, a.ldv, b, h, a.Lk, tid);
       // packed mask rows and "row sees a key" (both phases read them from LDS)
       for (int q = tid; q < LQP; q += ATT_THREADS) {
+        uint4 raw[(MW + 3) / 4] = {};
+        if (a.mbits) mask_row_raw<MW>(raw, a, b, q);
         uint32_t mw[MW];
-        mask_row<MW>(mw, a, b, q);
+        mask_row_use<MW>(mw, raw, a, q);
         uint32_t vis = 0;
 #pragma unroll
         for (int w = 0; w < MW; ++w) {
@@ -355,38 +387,43 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
         }
         rowok[q] = (q >= a.Lq) || vis != 0;
       }
-      sk.store(R0, LKP, 1.0f, tid);
-      sv.store(R1, LKP, 1.0f, tid);
+      sk.store(R0, a.Lk, LKP, tid);
+      sv.store(R1, a.Lk, LKP, tid);
     }
     __syncthreads();
+    float4 bk[NDT], bv[NDT];
+    bool tile_live = false;
     for (int u = wave; u < nqt; u += NW) {
       const int q = 16 * u + c16;
-      float4 bq[NDT], bd[NDT];
-      row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, q, g, a.scale);
-      row_frag_global<NDT>(bd, a.dout, a.ldo, b, h, a.Lq, q, g, 1.0f);
+      const bool real = q < a.Lq;
+      if (u != wave) {                   // more query tiles than waves (L > 96): load in place
+        row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, q, g);
+        row_frag_global<NDT>(bd, a.dout, a.ldo, b, h, a.Lq, q, g);
+        row_frag_global<NDT>(bo, a.o_in, a.ldo, b, h, a.Lq, q, g);
+        lse0 = a.lse_in[lrow0 + (real ? q : a.Lq - 1)];
+      }
       float del = 0.f;
       int nz = 0;
-      {
-        float4 bo[NDT];
-        row_frag_global<NDT>(bo, a.o_in, a.ldo, b, h, a.Lq, q, g, 1.0f);
 #pragma unroll
-        for (int j = 0; j < NDT; ++j) {
-          del += (bo[j].x * bd[j].x + bo[j].y * bd[j].y) + (bo[j].z * bd[j].z + bo[j].w * bd[j].w);
-          nz |= (bd[j].x != 0.f) | (bd[j].y != 0.f) | (bd[j].z != 0.f) | (bd[j].w != 0.f);
-        }
+      for (int j = 0; j < NDT; ++j) {
+        del += (bo[j].x * bd[j].x + bo[j].y * bd[j].y) + (bo[j].z * bd[j].z + bo[j].w * bd[j].w);
+        nz |= (bd[j].x != 0.f) | (bd[j].y != 0.f) | (bd[j].z != 0.f) | (bd[j].w != 0.f);
       }
       del += __shfl_xor(del, 16, 64);
       del += __shfl_xor(del, 32, 64);
       nz |= __shfl_xor(nz, 16, 64);
       nz |= __shfl_xor(nz, 32, 64);
-      const float lse = q < a.Lq ? a.lse_in[lrow0 + q] : 0.f;
+      del = real ? del : 0.f;            // rows beyond Lq hold a copy of row Lq-1: neutralise
+      nz = real ? nz : 0;
+      const float lse = real ? lse0 : 0.f;
       if (g == 0) {
         del_s[q] = del;
         lse_s[q] = lse;
         rowlive[q] = (uint8_t)nz;
       }
-      if (!__any(nz)) {                       // all 16 gradient rows are zero: dQ rows = 0, nothing else
-        if (q < a.Lq) {
+      tile_live = __any(nz);
+      if (!tile_live) {                       // all 16 gradient rows are zero: dQ rows = 0, nothing else
+        if (real) {
           float* drow = a.dq + ((int64_t)b * a.Lq + q) * a.lddq + h * DK + 4 * g;
 #pragma unroll
           for (int dt = 0; dt < NDT; ++dt) *reinterpret_cast<float4*>(drow + 16 * dt) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -397,6 +434,10 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
 #pragma unroll
       for (int w = 0; w < MW; ++w) mw[w] = mb_s[q * MW + w];
       const uint32_t use = tiles_for_q<MW>(mw, q, a.Lq, a.Lk, nkt);
+      uint32_t rowvis = 0;
+#pragma unroll
+      for (int w = 0; w < MW; ++w) rowvis |= mw[w] & range_word(w, a.Lk);
+      const float masked = rowvis ? -1e9f : 0.f;        // see the forward's lse note
       f32x4 sacc[NT];                       // ends up holding dS^T
       const int64_t grow = lrow0 + q;
 #pragma unroll
@@ -407,7 +448,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
           {
             float4 ak[NDT];
             row_frag<NDT>(ak, R0, 16 * t + c16, g);
-            sacc[t] = dot_frag<NDT>(ak, bq, sacc[t]);  // S^T
+            sacc[t] = dot_frag<NDT>(ak, bq, sacc[t]);  // S^T (unscaled)
           }
           {
             float4 av[NDT];
@@ -415,14 +456,24 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
             pacc = dot_frag<NDT>(av, bd, pacc);        // dP^T
           }
           const uint32_t nib = mw[t >> 1] >> ((t & 1) * 16 + 4 * g);
-          uint4 bits = make_uint4(~0u, ~0u, ~0u, ~0u);
-          if (a.thr) bits = gct_philox(a.rng, (uint32_t)grow, (uint32_t)(4 * t + g), 0xA4093822u, 0x299F31D0u);
+          uint32_t keep = 0xfu;
+          if (a.thr) {
+            const uint4 bits = gct_philox(a.rng, (uint32_t)grow, (uint32_t)(4 * t + g), 0xA4093822u, 0x299F31D0u);
+            keep = (bits.x >= a.thr ? 1u : 0u) | (bits.y >= a.thr ? 2u : 0u) | (bits.z >= a.thr ? 4u : 0u) |
+                   (bits.w >= a.thr ? 8u : 0u);
+            // the keep bits of this (query row, 16 keys) go to LDS for phase B, which visits exactly the tiles
+            // visited here (same skip predicates): gather the four lane groups' nibbles, one 16-bit store per row
+            uint32_t hw = keep << (4 * g);
+            hw |= __shfl_xor(hw, 16, 64);
+            hw |= __shfl_xor(hw, 32, 64);
+            if (g == 0) kp_h[q * (2 * MW) + t] = (uint16_t)hw;
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const bool inr = 16 * t + 4 * g + r < a.Lk, vis = (nib >> r) & 1u;
-            const float p = inr ? __expf(score_of(sacc[t][r], true, vis) - lse) : 0.f;
-            const float dpd = (gct_pick(bits, r) >= a.thr) ? pacc[r] * a.keep_scale : 0.f;
-            sacc[t][r] = vis ? p * (dpd - del) : 0.f;  // dS^T (masked_fill passes no grad)
+            const float p = inr ? __expf(score_of(sacc[t][r] * a.scale, true, vis, masked) - lse) : 0.f;
+            const float dpd = ((keep >> r) & 1u) ? pacc[r] * a.keep_scale : 0.f;
+            sacc[t][r] = (inr && vis) ? p * (dpd - del) : 0.f;  // dS^T (masked_fill passes no grad)
           }
         }
       }
@@ -440,7 +491,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
             for (int dt = 0; dt < NDT; ++dt) qacc[dt] = mfma16(krow[16 * dt], bs, qacc[dt]);
           }
         }
-      if (q < a.Lq) {
+      if (real) {
         float* drow = a.dq + ((int64_t)b * a.Lq + q) * a.lddq + h * DK + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
@@ -448,67 +499,70 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
               make_float4(qacc[dt][0] * a.scale, qacc[dt][1] * a.scale, qacc[dt][2] * a.scale, qacc[dt][3] * a.scale);
       }
     }
-    __syncthreads();      // K, V no longer needed; del_s / lse_s / rowlive complete
+    constexpr bool FRAG_STAGE = NT <= NW;   // one query tile and one key tile per wave: stage through registers
+    if (FRAG_STAGE) {
+      // this wave's key tile of phase B: K / V rows are still in LDS
+      row_frag<NDT>(bk, R0, 16 * wave + c16, g);
+      row_frag<NDT>(bv, R1, 16 * wave + c16, g);
+    }
+    __syncthreads();      // K, V no longer needed; del_s / lse_s / rowlive / keep bits complete
     // ---------------------------------------------------------------- phase B: Q, dO in LDS -> dK, dV
-    {
+    if (FRAG_STAGE) {
+      // Q and dO cross HBM once: every wave still holds the rows of its query tile as fragments, in exactly the
+      // layout row_frag reads back (dead tiles are never read by phase B; rows beyond Lq are zeroed)
+      if (wave < nqt && tile_live) {
+        const int q = 16 * wave + c16;
+        const bool real = q < a.Lq;
+#pragma unroll
+        for (int j = 0; j < NDT; ++j) {
+          *reinterpret_cast<float4*>(R0 + q * SD + g * 4 * NDT + 4 * j) = real ? bq[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(R1 + q * SD + g * 4 * NDT + 4 * j) = real ? bd[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    } else {
       Stage<DK, NT> sq, sd;
       sq.load(a.q, a.ldq, b, h, a.Lq, tid);          // second read of this pair's Q / dO: L2
       sd.load(a.dout, a.ldo, b, h, a.Lq, tid);
-      if (a.thr) {
-        // keep bits of (q, 32 keys): 8 Philox calls, the same (row, 4-key group) counters as phase A / forward
-        for (int i = tid; i < LQP * MW; i += ATT_THREADS) {
-          const int q = i / MW, w = i - q * MW;
-          uint32_t word = 0;
-          if (q < a.Lq && rowlive[q]) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const int kg = 8 * w + e;
-              if (4 * kg < a.Lk) {
-                const uint4 bits = gct_philox(a.rng, (uint32_t)(lrow0 + q), (uint32_t)kg, 0xA4093822u, 0x299F31D0u);
-                const uint32_t nibk = (bits.x >= a.thr ? 1u : 0u) | (bits.y >= a.thr ? 2u : 0u) |
-                                      (bits.z >= a.thr ? 4u : 0u) | (bits.w >= a.thr ? 8u : 0u);
-                word |= nibk << (4 * e);
-              }
-            }
-          }
-          kp_s[i] = word;
-        }
-      }
-      sq.store(R0, LQP, a.scale, tid);
-      sd.store(R1, LQP, 1.0f, tid);
+      row_frag_global<NDT>(bk, a.k, a.ldk, b, h, a.Lk, 16 * wave + c16, g);
+      row_frag_global<NDT>(bv, a.v, a.ldv, b, h, a.Lk, 16 * wave + c16, g);
+      sq.store(R0, a.Lq, LQP, tid);
+      sd.store(R1, a.Lq, LQP, tid);
     }
     __syncthreads();
     for (int t = wave; t < nkt; t += NW) {
       const int k = 16 * t + c16;
+      if (t != wave) {
+        row_frag_global<NDT>(bk, a.k, a.ldk, b, h, a.Lk, k, g);
+        row_frag_global<NDT>(bv, a.v, a.ldv, b, h, a.Lk, k, g);
+      }
       f32x4 vacc[NDT], kacc[NDT];
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
         vacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         kacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-      float4 bk[NDT], bv[NDT];
-      row_frag_global<NDT>(bk, a.k, a.ldk, b, h, a.Lk, k, g, 1.0f);
-      row_frag_global<NDT>(bv, a.v, a.ldv, b, h, a.Lk, k, g, 1.0f);
       const int kw = k >> 5, kb = k & 31;
       const bool inr = k < a.Lk;
 #pragma unroll 1
       for (int u = 0; u < nqt; ++u) {
         if (!__any(rowlive[16 * u + c16] != 0)) continue;  // zero gradient rows: Pd^T dO = 0 and dS = 0
-        uint32_t vis4 = 0, keep4 = 0xfu;
+        uint32_t vis4 = 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qq = 16 * u + 4 * g + r;
-          vis4 |= ((mb_s[qq * MW + kw] >> kb) & 1u) << r;
-          if (a.thr) keep4 = (keep4 & ~(1u << r)) | (((kp_s[qq * MW + kw] >> kb) & 1u) << r);
-        }
+        for (int r = 0; r < 4; ++r) vis4 |= ((mb_s[(16 * u + 4 * g + r) * MW + kw] >> kb) & 1u) << r;
         const bool ok = __all(rowok[16 * u + c16] != 0);
-        if (ok && !__any(inr && vis4 != 0)) continue;       // fully masked tile: P = dS = 0
+        if (ok && !__any(inr && vis4 != 0)) continue;       // fully masked tile: P = dS = 0 (phase A skipped it too)
+        uint32_t keep4 = 0xfu;
+        if (a.thr) {
+          keep4 = 0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) keep4 |= ((kp_s[(16 * u + 4 * g + r) * MW + kw] >> kb) & 1u) << r;
+        }
         f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, pa = (f32x4){0.f, 0.f, 0.f, 0.f};
         {
           float4 aq[NDT], ad[NDT];
           row_frag<NDT>(aq, R0, 16 * u + c16, g);
           row_frag<NDT>(ad, R1, 16 * u + c16, g);
-          sa = dot_frag<NDT>(aq, bk, sa);   // S[q][k]
+          sa = dot_frag<NDT>(aq, bk, sa);   // S[q][k] (unscaled)
           pa = dot_frag<NDT>(ad, bv, pa);   // dP[q][k]
         }
         float pd[4], ds[4];
@@ -516,10 +570,10 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
         for (int r = 0; r < 4; ++r) {
           const int qq = 16 * u + 4 * g + r;
           const bool vis = (vis4 >> r) & 1u, keep = (keep4 >> r) & 1u;
-          const float p = inr ? __expf(score_of(sa[r], true, vis) - lse_s[qq]) : 0.f;
+          const float p = inr ? __expf(score_of(sa[r] * a.scale, true, vis, rowok[qq] ? -1e9f : 0.f) - lse_s[qq]) : 0.f;
           const float dpd = keep ? pa[r] * a.keep_scale : 0.f;
           pd[r] = keep ? p * a.keep_scale : 0.f;
-          ds[r] = vis ? p * (dpd - del_s[qq]) : 0.f;
+          ds[r] = (inr && vis) ? p * (dpd - del_s[qq]) : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -528,7 +582,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
 #pragma unroll
           for (int dt = 0; dt < NDT; ++dt) {
             vacc[dt] = mfma16(dorow[16 * dt], pd[r], vacc[dt]);  // dV^T[d][k] += dO[q][d] Pd[q][k]
-            kacc[dt] = mfma16(qrow[16 * dt], ds[r], kacc[dt]);   // dK^T[d][k] += Qs[q][d] dS[q][k]
+            kacc[dt] = mfma16(qrow[16 * dt], ds[r], kacc[dt]);   // dK^T[d][k] += Q[q][d] dS[q][k]
           }
         }
       }
@@ -538,7 +592,8 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
           *reinterpret_cast<float4*>(vrow + 16 * dt) = make_float4(vacc[dt][0], vacc[dt][1], vacc[dt][2], vacc[dt][3]);
-          *reinterpret_cast<float4*>(krow + 16 * dt) = make_float4(kacc[dt][0], kacc[dt][1], kacc[dt][2], kacc[dt][3]);
+          *reinterpret_cast<float4*>(krow + 16 * dt) =
+              make_float4(kacc[dt][0] * a.scale, kacc[dt][1] * a.scale, kacc[dt][2] * a.scale, kacc[dt][3] * a.scale);
         }
       }
     }

@@ -12,6 +12,7 @@
 //
 //   live[b,t]     = row (b,t) of g has a non-zero element
 //   violation     = exists (b,i,j): live[b,i] && !live[b,j] && mask[b,i,j] != 0      (dead key seen by a live query)
+//                   or a live row whose mask row is all zero next to any dead row     (uniform attention over ALL keys)
 //   non-prefix    = exists (b,t):   !live[b,t] && live[b,t+1]                        (live rows are not 0..n_b-1)
 //
 // gct_live_rows also emits what the shortcuts consume: per-sample counts and offsets, the ascending list of live
@@ -63,6 +64,18 @@ __global__ __launch_bounds__(256) void live_flags_kernel(const float* __restrict
       const int i = idx / T, j = idx - i * T;
       if (lv[i] && !lv[j] && mb[(int64_t)i * mask_sq + j]) viol = 1;
     }
+    // a live row that sees NO key attends uniformly to every key (masked_fill(-1e9) on the whole row), dead ones
+    // included: their dV is non-zero
+    int anyd = 0;
+    for (int t = tid; t < T; t += 256) anyd |= !lv[t];
+    anyd = __syncthreads_or(anyd);
+    if (anyd)
+      for (int i = tid; i < T; i += 256)
+        if (lv[i]) {
+          int seen = 0;
+          for (int j = 0; j < T && !seen; ++j) seen = mb[(int64_t)i * mask_sq + j] != 0;
+          if (!seen) viol = 1;
+        }
     viol = __syncthreads_or(viol);
   }
   cnt = (int)gct_wave_sum((float)cnt);

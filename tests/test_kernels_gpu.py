@@ -162,7 +162,8 @@ def ref_attention(q, k, v, mask, scale, keep=None, pkeep=1.0):
                                                (1, 8, 80, 80, 64, "pad"), (3, 2, 97, 120, 16, "pad"),
                                                (2, 8, 171, 171, 64, "causal"), (2, 8, 171, 173, 64, "pad"),
                                                (1, 4, 200, 200, 64, "causal"), (2, 2, 5, 208, 32, "none"),
-                                               (2, 4, 203, 198, 16, "pad")])
+                                               (2, 4, 203, 198, 16, "pad"), (2, 4, 40, 37, 16, "holes"),
+                                               (2, 8, 81, 81, 64, "holes")])
 def test_attention(ops, B, H, Lq, Lk, dk, mode):
     d = H * dk
     qkv = rnd(B * max(Lq, Lk), 3 * d, seed=1)
@@ -177,6 +178,13 @@ def test_attention(ops, B, H, Lq, Lk, dk, mode):
     elif mode == "causal":
         pad = (torch.arange(Lk)[None, :] < lens[:, None])
         mask = (pad[:, None, :] & torch.tril(torch.ones(Lq, Lk, dtype=torch.bool))[None]).to(torch.uint8)
+        mfull = mask[:, None]
+    elif mode == "holes":
+        # arbitrary mask with query rows that see NO key (masked_fill(-1e9) on the whole row => uniform attention,
+        # gradient flows to V only) next to ordinary rows -- the left-padded-batch situation
+        mask = (torch.rand(B, Lq, Lk, generator=torch.Generator().manual_seed(8)) < 0.6).to(torch.uint8)
+        mask[:, ::3, :] = 0
+        mask[:, 1, 5:] = 0
         mfull = mask[:, None]
     else:
         mask, mfull = None, None

@@ -424,7 +424,9 @@ def test_zero_gradient_rows_with_arbitrary_masks_vs_oracle(case):
     rows (% 32 == 0) with >= 32 consecutive zero-gradient rows in every case; all gradients against the oracle.
       last_token_loss : causal mask, loss on the last position only -> live query sees 63 dead keys (guard must trip)
       no_trg_mask     : trg_mask=None, padded ys                   -> dead rows are visible keys    (guard must trip)
-      left_padded     : tokens right-aligned, pad & causal mask    -> dead rows invisible, NOT a prefix (shortcut ok)
+      left_padded     : tokens right-aligned, pad & causal mask    -> the first live row of a sample (target <sos>, its own
+                        input is <pad>) sees NO key: masked_fill gives it uniform attention over ALL keys, dead ones
+                        included, so they do receive dV                                            (guard must trip)
       right_padded_reference : the reference's own masks            -> shortcut taken"""
     from gct_plus_amd import ops
     from gct_plus_amd.Model import get_src_mask, get_trg_mask
@@ -483,11 +485,11 @@ def test_zero_gradient_rows_with_arbitrary_masks_vs_oracle(case):
         dead_run = max(dead_run, run_len)
     assert dead_run >= 32, dead_run
     assert h["n_live"] == int((ys != PAD).sum())
-    if case in ("last_token_loss", "no_trg_mask"):
+    if case in ("last_token_loss", "no_trg_mask", "left_padded"):
         assert h["violations"] > 0 and h["tiles"] == B * T // 32      # every tile listed: dense reduction
     else:
         assert h["violations"] == 0 and h["tiles"] < B * T // 32      # shortcut in force
-        assert (h["nonprefix"] > 0) == (case == "left_padded")
+    assert (h["nonprefix"] > 0) == (case in ("left_padded", "last_token_loss"))
     loss.backward()
     oloss.backward()
     floor = grad_floor(v.grad for v in P.values())

@@ -59,7 +59,7 @@ def gemm_suite(reps, only=None):
                   flush=True)
 
 
-def attn_suite(reps):
+def attn_suite(reps, fixed=False):
     dev = "cuda"
     for name, B, H, Lq, Lk, dk, causal in (("enc", 512, 8, 80, 80, 64, False), ("dec", 512, 8, 81, 81, 64, True),
                                            ("cross", 512, 8, 81, 80, 64, False)):
@@ -68,21 +68,25 @@ def attn_suite(reps):
         # MOSES-like ragged lengths: l ~ N(35,8) clipped to [15, L]
         lens = torch.clamp(torch.round(torch.randn(B, device=dev) * 8 + 35), 15, Lk).long()
         lens[0] = Lk
+        if fixed:
+            lens[:] = Lk
         pad = (torch.arange(Lk, device=dev)[None, :] < lens[:, None])
         if causal:
             mask = (pad[:, None, :] & torch.ones(Lq, Lk, dtype=torch.bool, device=dev).tril_()[None]).to(torch.uint8).contiguous()
         else:
             mask = pad.to(torch.uint8).contiguous()
         q, k, v = qkv, qkv[:, d:], qkv[:, 2 * d:]
+        mask = ops.pack_mask(mask, B, Lq, Lk)        # packed once per forward in the engine, not per call
         o, lse, _ = ops.attn_fwd(q, k, v, 3 * d, 3 * d, 3 * d, mask, B, H, Lq, Lk, dk, 0.1, 1, 1)
         do = torch.randn_like(o)
         dqkv = torch.empty_like(qkv)
         fl = 4.0 * B * H * Lq * Lk * dk
         med, best = timeit(lambda: ops.attn_fwd(q, k, v, 3 * d, 3 * d, 3 * d, mask, B, H, Lq, Lk, dk, 0.1, 1, 1), reps)
-        print(f"attn {name:5s} fwd: {med*1e6:8.1f} us  {fl/med/1e12:6.2f} TF", flush=True)
+        gb = 4.0 * B * max(Lq, Lk) * d * 4
+        print(f"attn {name:5s} fwd{' fixed' if fixed else ''}: {med*1e6:8.1f} us  {fl/med/1e12:6.2f} TF  {gb/med/1e9:7.0f} GB/s", flush=True)
         med, best = timeit(lambda: ops.attn_bwd(q, k, v, 3 * d, 3 * d, 3 * d, mask, o, do, lse, dqkv, dqkv[:, d:],
                                                 dqkv[:, 2 * d:], 3 * d, 3 * d, 3 * d, B, H, Lq, Lk, dk, 0.1, 1, 1), reps)
-        print(f"attn {name:5s} bwd: {med*1e6:8.1f} us  {2.5*fl/med/1e12:6.2f} TF", flush=True)
+        print(f"attn {name:5s} bwd{' fixed' if fixed else ''}: {med*1e6:8.1f} us  {2.5*fl/med/1e12:6.2f} TF  {2*gb/med/1e9:7.0f} GB/s", flush=True)
 
 
 def bw_suite(reps):
@@ -114,5 +118,6 @@ if __name__ == "__main__":
         gemm_suite(a.reps, a.only.split(",") if a.only else None)
     if "attn" in a.suite:
         attn_suite(a.reps)
+        attn_suite(a.reps, fixed=True)
     if "bw" in a.suite:
         bw_suite(a.reps)
