@@ -43,23 +43,50 @@ constexpr int MASK_W = 8;              // packed mask: 8 x 32 bits per query row
 constexpr int L_MAX = 208;             // 13 tiles of 16: covers the reference's 200-row positional table + 3 conditions
 
 struct AttnArgs {
+  // strides are 32-bit (checked on the host): 64-bit strides cost SGPRs this kernel does not have to spare -- they
+  // were spilled into VGPR lanes (v_readlane on every use)
   const float *q, *k, *v;
-  int64_t ldq, ldk, ldv;
+  int ldq, ldk, ldv;
   const uint32_t* mbits;               // packed mask rows (nullable = everything visible)
-  int64_t mb_sb, mb_sq;                // strides in words: per batch, per query row (0: key-padding mask)
+  int mb_sb, mb_sq;                    // strides in words: per batch, per query row (0: key-padding mask)
   float* o;
-  int64_t ldo;
+  int ldo;
   float* lse;
   float* probs;
   // backward
   const float *o_in, *dout, *lse_in;
   float *dq, *dk, *dv;
-  int64_t lddq, lddk, lddv;
+  int lddq, lddk, lddv;
   int B, H, Lq, Lk, npairs;
   float scale, keep_scale;
   uint32_t thr;
   GctRng rng;
+#ifdef GCT_STAMPS
+  unsigned long long* stamps;
+#endif
 };
+
+// Diagnostic build only (tools/attn_stamps.hip, -DGCT_STAMPS): s_memtime at the pipeline's seams, summed per wave.
+#ifdef GCT_STAMPS
+#define ASTAMP_DECL unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev; \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory")
+#define ASTAMP(i)                                                                      \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    unsigned long long t__;                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");         \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    seg[i] += t__ - tprev;                                                             \
+    tprev = t__;                                                                       \
+  } while (0)
+#define ASTAMP_OUT                                                                     \
+  if (a.stamps && (threadIdx.x & 63) == 0 && blockIdx.x < 64)                          \
+    for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * (ATT_THREADS / 64) + (threadIdx.x >> 6)) * 8 + i] = seg[i]
+#else
+#define ASTAMP_DECL
+#define ASTAMP(i)
+#define ASTAMP_OUT
+#endif
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -71,18 +98,29 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // half): anything that consumes a loaded register makes the wave wait for it AND for every older load (vmcnt is
 // in-order), which would turn the prefetch into a stall.
 template <int DK, int NT>
-struct Stage {
-  static constexpr int SD = DK + 4, C = DK / 4;
-  static constexpr int ITERS = (16 * NT * C + ATT_THREADS - 1) / ATT_THREADS;
-  float4 v[ITERS];
-  __device__ __forceinline__ void load(const float* src, int64_t ld, int b, int h, int L, int tid) {
+struct StageOff {           // BYTE offsets of a thread's chunks inside a pair's [L][ld] slice (pair independent):
+  static constexpr int C = DK / 4;                                 // unsigned 32 bit => global_load with a scalar
+  static constexpr int ITERS = (16 * NT * C + ATT_THREADS - 1) / ATT_THREADS;    // base and a 32-bit vector offset
+  uint32_t off[ITERS];
+  __device__ __forceinline__ void init(int ld, int L, int tid) {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int idx = tid + it * ATT_THREADS;
       const int r = idx / C, c = idx - r * C;
-      const int rr = r < L ? r : L - 1;
-      v[it] = *reinterpret_cast<const float4*>(src + ((int64_t)b * L + rr) * ld + h * DK + c * 4);
+      off[it] = (uint32_t)(((r < L ? r : L - 1) * ld + c * 4) * 4);
     }
+  }
+};
+template <int DK, int NT>
+struct Stage {
+  static constexpr int SD = DK + 4, C = DK / 4;
+  static constexpr int ITERS = StageOff<DK, NT>::ITERS;
+  float4 v[ITERS];
+  __device__ __forceinline__ void load(const float* src, int ld, int b, int h, int L, const StageOff<DK, NT>& o) {
+    const float* base = src + (int64_t)b * L * ld + h * DK;      // wave-uniform
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+      v[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + o.off[it]);
   }
   __device__ __forceinline__ void store(float* dst, int L, int LP, int tid) const {
 #pragma unroll
@@ -110,12 +148,13 @@ __device__ __forceinline__ void row_frag(float4 (&f)[NDT], const float* lds, int
 // L-1 (finite values; every consumer discards or masks what such rows produce) -- no select on the loaded data,
 // see Stage.
 template <int NDT>
-__device__ __forceinline__ void row_frag_global(float4 (&f)[NDT], const float* src, int64_t ld, int b, int h, int L,
+__device__ __forceinline__ void row_frag_global(float4 (&f)[NDT], const float* src, int ld, int b, int h, int L,
                                                 int row, int g) {
   const int rr = row < L ? row : L - 1;
-  const float* p = src + ((int64_t)b * L + rr) * ld + h * 16 * NDT + g * 4 * NDT;
+  const char* base = reinterpret_cast<const char*>(src + (int64_t)b * L * ld + h * 16 * NDT);   // wave-uniform
+  const uint32_t off = (uint32_t)((rr * ld + g * 4 * NDT) * 4);                                   // per lane
 #pragma unroll
-  for (int j = 0; j < NDT; ++j) f[j] = *reinterpret_cast<const float4*>(p + 4 * j);
+  for (int j = 0; j < NDT; ++j) f[j] = *reinterpret_cast<const float4*>(base + off + 16 * j);
 }
 template <int NDT>
 __device__ __forceinline__ f32x4 dot_frag(const float4 (&a)[NDT], const float4 (&b)[NDT], f32x4 acc) {
@@ -139,9 +178,10 @@ __device__ __forceinline__ uint32_t range_word(int w, int Lk) {
 template <int MW>
 __device__ __forceinline__ void mask_row_raw(uint4 (&raw)[(MW + 3) / 4], const AttnArgs& a, int b, int q) {
   const int qq = q < a.Lq ? q : a.Lq - 1;
-  const uint4* p = reinterpret_cast<const uint4*>(a.mbits + (int64_t)b * a.mb_sb + (int64_t)qq * a.mb_sq);
+  const char* base = reinterpret_cast<const char*>(a.mbits + (int64_t)b * a.mb_sb);              // wave-uniform
+  const uint32_t off = (uint32_t)(qq * a.mb_sq * 4);
 #pragma unroll
-  for (int w4 = 0; w4 < (MW + 3) / 4; ++w4) raw[w4] = p[w4];
+  for (int w4 = 0; w4 < (MW + 3) / 4; ++w4) raw[w4] = *reinterpret_cast<const uint4*>(base + off + 16 * w4);
 }
 // ... and their use: all ones without a mask or beyond Lq
 template <int MW>
@@ -175,6 +215,30 @@ __device__ __forceinline__ uint32_t tiles_for_q(const uint32_t (&mw)[MW], int q,
   return __builtin_amdgcn_readfirstlane(use);
 }
 
+// Dropout keep bits of one query row for the key tiles in `use`: bit 4t + r <=> key 16t + 4g + r is kept.  One
+// Philox call serves the lane's 4 keys of TWO adjacent tiles: key r of tile t takes the 16-bit lane (t & 1) * 4 + r of
+// philox(row, (t >> 1) * 4 + g) and is kept iff that lane >= thr >> 16 (P(drop) = floor(p * 2^16) / 2^16, the
+// convention of the GEMM epilogues' dropout).  The loop is kept ROLLED: one call's registers live at a time.
+template <int NT>
+__device__ __forceinline__ uint64_t keep_bits_row(const AttnArgs& a, uint32_t grow, uint32_t use, int g) {
+  uint64_t keep = ~0ull;
+  if (a.thr) {
+    keep = 0;
+    const uint32_t th = a.thr >> 16;
+#pragma unroll 1
+    for (int t2 = 0; t2 < (NT + 1) / 2; ++t2)
+      if ((use >> (2 * t2)) & 3u) {
+        const uint4 bits = gct_philox(a.rng, grow, (uint32_t)(4 * t2 + g), 0xA4093822u, 0x299F31D0u);
+        const uint32_t byte = ((bits.x & 0xffffu) >= th ? 1u : 0u) | ((bits.x >> 16) >= th ? 2u : 0u) |
+                              ((bits.y & 0xffffu) >= th ? 4u : 0u) | ((bits.y >> 16) >= th ? 8u : 0u) |
+                              ((bits.z & 0xffffu) >= th ? 16u : 0u) | ((bits.z >> 16) >= th ? 32u : 0u) |
+                              ((bits.w & 0xffffu) >= th ? 64u : 0u) | ((bits.w >> 16) >= th ? 128u : 0u);
+        keep |= (uint64_t)byte << (8 * t2);
+      }
+  }
+  return keep;
+}
+
 __device__ __forceinline__ float score_of(float s, bool in_range, bool visible, float masked = -1e9f) {
   return in_range ? (visible ? s : masked) : -INFINITY;
 }
@@ -183,7 +247,7 @@ __device__ __forceinline__ float score_of(float s, bool in_range, bool visible, 
 // One query tile (16 rows) of one pair: S^T, softmax, P.V.  bq = this lane's RAW Q fragment (the 1/sqrt(dk) is
 // applied to the scores, after the product, like the reference's `matmul(q, k^T) / sqrt(d_k)`); mw = the packed
 // mask words of this lane's query row.
-template <int NDT, int NT, typename AfterS>
+template <int NDT, int NT, bool PROBS, typename AfterS>
 __device__ __forceinline__ void fwd_unit(const AttnArgs& a, int b, int h, int u, float4 (&bq)[NDT],
                                          const uint32_t (&mw)[(NT + 1) / 2], const float* Ks, const float* Vs, int nkt,
                                          int lane, AfterS after_s) {
@@ -206,11 +270,12 @@ __device__ __forceinline__ void fwd_unit(const AttnArgs& a, int b, int h, int u,
       sacc[t] = dot_frag<NDT>(ak, bq, sacc[t]);
     }
   after_s();          // bq is dead from here on: the caller may reload it (next pair's rows)
-  // scale + mask + softmax over keys (regs x tiles in-lane, then lanes l^16, l^32)
+  // scale + mask + softmax over keys (regs x tiles in-lane, then lanes l^16, l^32).  Tiles outside `use` hold
+  // only masked keys of rows that see a key elsewhere: probability exactly 0, nothing to compute.
   float m = -INFINITY;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
-    if (t < nkt) {
+    if ((use >> t) & 1u) {
       const uint32_t nib = mw[t >> 1] >> ((t & 1) * 16 + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -225,7 +290,7 @@ __device__ __forceinline__ void fwd_unit(const AttnArgs& a, int b, int h, int u,
   float l = 0.f;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
-    if (t < nkt) {
+    if ((use >> t) & 1u) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float e = __expf(sacc[t][r] - m);
@@ -239,18 +304,19 @@ __device__ __forceinline__ void fwd_unit(const AttnArgs& a, int b, int h, int u,
   const int64_t grow = ((int64_t)b * a.H + h) * a.Lq + q;
   // A row without a visible key is uniform over its Lk keys (every score -1e9).  -1e9 + log(Lk) is not
   // representable in fp32, so such a row stores log(Lk) and the backward scores its masked keys as 0, not -1e9.
-  if (g == 0 && q < a.Lq) a.lse[grow] = (rowvis ? m : 0.f) + __logf(l);
+  if (g == 0 && q < a.Lq) (a.lse + ((int64_t)b * a.H + h) * a.Lq)[q] = (rowvis ? m : 0.f) + __logf(l);
+  const uint64_t keep = keep_bits_row<NT>(a, (uint32_t)grow, use, g);
 #pragma unroll
   for (int t = 0; t < NT; ++t)
     if (t < nkt) {
-      uint4 bits = make_uint4(~0u, ~0u, ~0u, ~0u);
-      if (a.thr && ((use >> t) & 1u)) bits = gct_philox(a.rng, (uint32_t)grow, (uint32_t)(4 * t + g), 0xA4093822u, 0x299F31D0u);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = sacc[t][r] * inv;
         const int k = 16 * t + 4 * g + r;
-        if (a.probs && q < a.Lq && k < a.Lk) a.probs[grow * a.Lk + k] = p;
-        sacc[t][r] = (gct_pick(bits, r) >= a.thr) ? p * a.keep_scale : 0.f;
+        // (this runtime branch also bounds the scheduling region: with it compiled out, hipcc 7.2 interleaves the loop
+        //  with the P.V product below and spills ~200 dwords per lane)
+        if (PROBS && a.probs && q < a.Lq && k < a.Lk) a.probs[grow * a.Lk + k] = p;
+        sacc[t][r] = ((keep >> (4 * t + r)) & 1ull) ? p * a.keep_scale : 0.f;
       }
     }
   // O^T[d][q] = sum_k V[k][d] * Pdrop^T[k][q]
@@ -269,15 +335,16 @@ __device__ __forceinline__ void fwd_unit(const AttnArgs& a, int b, int h, int u,
       }
     }
   if (q < a.Lq) {
-    float* orow = a.o + ((int64_t)b * a.Lq + q) * a.ldo + h * DK + 4 * g;
+    char* obase = reinterpret_cast<char*>(a.o + (int64_t)b * a.Lq * a.ldo + h * DK);             // wave-uniform
+    const uint32_t ooff = (uint32_t)((q * a.ldo + 4 * g) * 4);
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
-      *reinterpret_cast<float4*>(orow + 16 * dt) = make_float4(oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]);
+      *reinterpret_cast<float4*>(obase + ooff + 64 * dt) = make_float4(oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]);
   }
 }
 
-template <int NDT, int NT, bool PIPE>
-__global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_fwd_kernel(const AttnArgs a) {
+template <int NDT, int NT, bool PIPE, int OCC>
+__global__ __launch_bounds__(ATT_THREADS, OCC) void attn_fwd_kernel(const AttnArgs a) {
   constexpr int DK = 16 * NDT, SD = DK + 4, NW = ATT_THREADS / 64, MW = (NT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
@@ -287,32 +354,39 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_fwd_kerne
   int pair = blockIdx.x;
   if (pair >= a.npairs) return;
   Stage<DK, NT> sk, sv;
+  StageOff<DK, NT> kvo;                  // ldk == ldv (checked on the host): one offset set serves K and V
+  kvo.init(a.ldk, a.Lk, tid);
   float4 bq[NDT];
   uint4 mraw[(MW + 3) / 4] = {};
   {
     const int b = pair / a.H, h = pair - b * a.H;
-    sk.load(a.k, a.ldk, b, h, a.Lk, tid);
-    sv.load(a.v, a.ldv, b, h, a.Lk, tid);
+    sk.load(a.k, a.ldk, b, h, a.Lk, kvo);
+    sv.load(a.v, a.ldv, b, h, a.Lk, kvo);
     row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, 16 * wave + c16, g);
     if (a.mbits) mask_row_raw<MW>(mraw, a, b, 16 * wave + c16);
   }
+  ASTAMP_DECL;
   for (;;) {
     const int b = pair / a.H, h = pair - b * a.H;
+    ASTAMP(0);                           // loop seam
     sk.store(Ks, a.Lk, LKP, tid);
     sv.store(Vs, a.Lk, LKP, tid);
     uint32_t mw[MW];
     mask_row_use<MW>(mw, mraw, a, 16 * wave + c16);
+    ASTAMP(1);                           // wait for the staged K / V + LDS stores
     __syncthreads();
+    ASTAMP(2);                           // barrier 1
     const int next = pair + (int)gridDim.x;
     const bool more = next < a.npairs;
     const int nb = more ? next / a.H : b, nh = more ? next - nb * a.H : h;
     // Next pair's operands: requested now, consumed at the top of the next iteration.  NOTHING loaded below this
     // point may be consumed before then (a wait on a younger load waits for these too).
     if (PIPE && more) {
-      sk.load(a.k, a.ldk, nb, nh, a.Lk, tid);
-      sv.load(a.v, a.ldv, nb, nh, a.Lk, tid);
+      sk.load(a.k, a.ldk, nb, nh, a.Lk, kvo);
+      sv.load(a.v, a.ldv, nb, nh, a.Lk, kvo);
       if (a.mbits) mask_row_raw<MW>(mraw, a, nb, 16 * wave + c16);
     }
+    ASTAMP(3);                           // prefetch issue
     for (int u = wave; u < nqt; u += NW) {
       if (u != wave) {                   // only when there are more query tiles than waves (L > 96)
         row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, 16 * u + c16, g);
@@ -321,22 +395,25 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_fwd_kerne
         mask_row_use<MW>(mw, r2, a, 16 * u + c16);
       }
       const bool last = u + NW >= nqt;
-      fwd_unit<NDT, NT>(a, b, h, u, bq, mw, Ks, Vs, nkt, lane, [&]() {
+      fwd_unit<NDT, NT, true>(a, b, h, u, bq, mw, Ks, Vs, nkt, lane, [&]() {
         // S^T was bq's last use: this wave's Q rows of the next pair arrive during softmax and P.V
         if (PIPE && more && last) row_frag_global<NDT>(bq, a.q, a.ldq, nb, nh, a.Lq, 16 * wave + c16, g);
       });
     }
     if (PIPE && more && wave >= nqt) row_frag_global<NDT>(bq, a.q, a.ldq, nb, nh, a.Lq, 16 * wave + c16, g);
+    ASTAMP(4);                           // compute
     if (!more) break;
     __syncthreads();                     // every wave is done reading Ks / Vs
+    ASTAMP(5);                           // barrier 2
     if (!PIPE) {
-      sk.load(a.k, a.ldk, nb, nh, a.Lk, tid);
-      sv.load(a.v, a.ldv, nb, nh, a.Lk, tid);
+      sk.load(a.k, a.ldk, nb, nh, a.Lk, kvo);
+      sv.load(a.v, a.ldv, nb, nh, a.Lk, kvo);
       row_frag_global<NDT>(bq, a.q, a.ldq, nb, nh, a.Lq, 16 * wave + c16, g);
       if (a.mbits) mask_row_raw<MW>(mraw, a, nb, 16 * wave + c16);
     }
     pair = next;
   }
+  ASTAMP_OUT;
 }
 
 // ----------------------------------------------------------------------------- backward
@@ -357,6 +434,8 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
   uint16_t* kp_h = reinterpret_cast<uint16_t*>(kp_s);             //   ... as one 16-bit half-word per (q, key tile)
   uint8_t* rowok = reinterpret_cast<uint8_t*>(kp_s + LQP * MW);   // [LQP] row sees a key (or is padding)
   uint8_t* rowlive = rowok + LQP;                                 // [LQP] dO row has a non-zero element
+  StageOff<DK, NT> kvo;                  // ldk == ldv (checked on the host)
+  kvo.init(a.ldk, a.Lk, tid);
   for (int pair = blockIdx.x; pair < a.npairs; pair += (int)gridDim.x) {
     const int b = pair / a.H, h = pair - b * a.H;
     const int64_t lrow0 = ((int64_t)b * a.H + h) * a.Lq;
@@ -371,8 +450,8 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
     float lse0 = a.lse_in[lrow0 + (q0 < a.Lq ? q0 : a.Lq - 1)];
     {
       Stage<DK, NT> sk, sv;
-      sk.load(a.k, a.ldk, b, h, a.Lk, tid);
-      sv.load(a.v, a.ldv, b, h, a.Lk, tid);
+      sk.load(a.k, a.ldk, b, h, a.Lk, kvo);
+      sv.load(a.v, a.ldv, b, h, a.Lk, kvo);
       // packed mask rows and "row sees a key" (both phases read them from LDS)
       for (int q = tid; q < LQP; q += ATT_THREADS) {
         uint4 raw[(MW + 3) / 4] = {};
@@ -424,9 +503,10 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
       tile_live = __any(nz);
       if (!tile_live) {                       // all 16 gradient rows are zero: dQ rows = 0, nothing else
         if (real) {
-          float* drow = a.dq + ((int64_t)b * a.Lq + q) * a.lddq + h * DK + 4 * g;
+          char* dbase = reinterpret_cast<char*>(a.dq + (int64_t)b * a.Lq * a.lddq + h * DK);
+          const uint32_t doff = (uint32_t)((q * a.lddq + 4 * g) * 4);
 #pragma unroll
-          for (int dt = 0; dt < NDT; ++dt) *reinterpret_cast<float4*>(drow + 16 * dt) = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int dt = 0; dt < NDT; ++dt) *reinterpret_cast<float4*>(dbase + doff + 64 * dt) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         continue;
       }
@@ -440,6 +520,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
       const float masked = rowvis ? -1e9f : 0.f;        // see the forward's lse note
       f32x4 sacc[NT];                       // ends up holding dS^T
       const int64_t grow = lrow0 + q;
+      const uint64_t keepw = keep_bits_row<NT>(a, (uint32_t)grow, use, g);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -456,11 +537,8 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
             pacc = dot_frag<NDT>(av, bd, pacc);        // dP^T
           }
           const uint32_t nib = mw[t >> 1] >> ((t & 1) * 16 + 4 * g);
-          uint32_t keep = 0xfu;
+          const uint32_t keep = (uint32_t)(keepw >> (4 * t)) & 0xfu;
           if (a.thr) {
-            const uint4 bits = gct_philox(a.rng, (uint32_t)grow, (uint32_t)(4 * t + g), 0xA4093822u, 0x299F31D0u);
-            keep = (bits.x >= a.thr ? 1u : 0u) | (bits.y >= a.thr ? 2u : 0u) | (bits.z >= a.thr ? 4u : 0u) |
-                   (bits.w >= a.thr ? 8u : 0u);
             // the keep bits of this (query row, 16 keys) go to LDS for phase B, which visits exactly the tiles
             // visited here (same skip predicates): gather the four lane groups' nibbles, one 16-bit store per row
             uint32_t hw = keep << (4 * g);
@@ -492,10 +570,11 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
           }
         }
       if (real) {
-        float* drow = a.dq + ((int64_t)b * a.Lq + q) * a.lddq + h * DK + 4 * g;
+        char* dbase = reinterpret_cast<char*>(a.dq + (int64_t)b * a.Lq * a.lddq + h * DK);
+        const uint32_t doff = (uint32_t)((q * a.lddq + 4 * g) * 4);
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
-          *reinterpret_cast<float4*>(drow + 16 * dt) =
+          *reinterpret_cast<float4*>(dbase + doff + 64 * dt) =
               make_float4(qacc[dt][0] * a.scale, qacc[dt][1] * a.scale, qacc[dt][2] * a.scale, qacc[dt][3] * a.scale);
       }
     }
@@ -521,8 +600,11 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
       }
     } else {
       Stage<DK, NT> sq, sd;
-      sq.load(a.q, a.ldq, b, h, a.Lq, tid);          // second read of this pair's Q / dO: L2
-      sd.load(a.dout, a.ldo, b, h, a.Lq, tid);
+      StageOff<DK, NT> qo, dof;
+      qo.init(a.ldq, a.Lq, tid);
+      dof.init(a.ldo, a.Lq, tid);
+      sq.load(a.q, a.ldq, b, h, a.Lq, qo);           // second read of this pair's Q / dO: L2
+      sd.load(a.dout, a.ldo, b, h, a.Lq, dof);
       row_frag_global<NDT>(bk, a.k, a.ldk, b, h, a.Lk, 16 * wave + c16, g);
       row_frag_global<NDT>(bv, a.v, a.ldv, b, h, a.Lk, 16 * wave + c16, g);
       sq.store(R0, a.Lq, LQP, tid);
@@ -587,12 +669,13 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
         }
       }
       if (k < a.Lk) {
-        float* vrow = a.dv + ((int64_t)b * a.Lk + k) * a.lddv + h * DK + 4 * g;
-        float* krow = a.dk + ((int64_t)b * a.Lk + k) * a.lddk + h * DK + 4 * g;
+        char* vbase = reinterpret_cast<char*>(a.dv + (int64_t)b * a.Lk * a.lddv + h * DK);
+        char* kbase = reinterpret_cast<char*>(a.dk + (int64_t)b * a.Lk * a.lddk + h * DK);
+        const uint32_t voff = (uint32_t)((k * a.lddv + 4 * g) * 4), koff = (uint32_t)((k * a.lddk + 4 * g) * 4);
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-          *reinterpret_cast<float4*>(vrow + 16 * dt) = make_float4(vacc[dt][0], vacc[dt][1], vacc[dt][2], vacc[dt][3]);
-          *reinterpret_cast<float4*>(krow + 16 * dt) =
+          *reinterpret_cast<float4*>(vbase + voff + 64 * dt) = make_float4(vacc[dt][0], vacc[dt][1], vacc[dt][2], vacc[dt][3]);
+          *reinterpret_cast<float4*>(kbase + koff + 64 * dt) =
               make_float4(kacc[dt][0] * a.scale, kacc[dt][1] * a.scale, kacc[dt][2] * a.scale, kacc[dt][3] * a.scale);
         }
       }
@@ -651,6 +734,10 @@ int check_common(const char* who, const float* q, int64_t ldq, const float* k, i
   GCT_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && gct_aligned16(q) &&
                     gct_aligned16(k) && gct_aligned16(v),
                 "%s: q/k/v must be 16-B aligned with ld %% 4 == 0", who);
+  GCT_CHECK_ARG(ldk == ldv, "%s: k and v must share one leading dimension (ldk %lld, ldv %lld)", who, (long long)ldk,
+                (long long)ldv);
+  GCT_CHECK_ARG((int64_t)(Lq > Lk ? Lq : Lk) * (ldq > ldk ? ldq : ldk) * 4 < (1ll << 31) && mb_sb < (1ll << 30),
+                "%s: one (batch) slice exceeds 2 GiB", who);
   GCT_CHECK_ARG(!mbits || (gct_aligned16(mbits) && mb_sb % 4 == 0 && mb_sq % 4 == 0),
                 "%s: packed mask rows must be 16-B aligned (use gct_attn_mask_pack)", who);
   GCT_CHECK_ARG(p >= 0.f && p < 1.f, "%s: dropout p out of range", who);
@@ -659,11 +746,20 @@ int check_common(const char* who, const float* q, int64_t ldq, const float* k, i
 }
 
 template <int NDT, int NT>
-int launch_fwd(const AttnArgs& a, size_t lds, unsigned grid, hipStream_t st) {
-  constexpr bool PIPE = NT <= 8;
-  int rc = ensure_lds(attn_fwd_kernel<NDT, NT, PIPE>, lds);
-  if (rc) return rc;
-  hipLaunchKernelGGL((attn_fwd_kernel<NDT, NT, PIPE>), dim3(grid), dim3(ATT_THREADS), lds, st, a);
+int launch_fwd(const AttnArgs& a, size_t lds, hipStream_t st) {
+  // persistent workgroups: as many as are resident together (2 per CU: 6 waves at <= 168 VGPRs)
+  const int per_cu = NT > 8 ? 1 : 2;
+  const int64_t want = (int64_t)num_cus() * per_cu;
+  const unsigned grid = (unsigned)(a.npairs < want ? a.npairs : want);
+  if constexpr (NT > 8) {
+    int rc = ensure_lds(attn_fwd_kernel<NDT, NT, false, 2>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_fwd_kernel<NDT, NT, false, 2>), dim3(grid), dim3(ATT_THREADS), lds, st, a);
+  } else {
+    int rc = ensure_lds(attn_fwd_kernel<NDT, NT, true, 3>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_fwd_kernel<NDT, NT, true, 3>), dim3(grid), dim3(ATT_THREADS), lds, st, a);
+  }
   return GCT_OK;
 }
 template <int NDT, int NT>
@@ -674,9 +770,8 @@ int launch_bwd(const AttnArgs& a, size_t lds, unsigned grid, hipStream_t st) {
   return GCT_OK;
 }
 template <int NT>
-int launch_fwd_dk(int dk, const AttnArgs& a, size_t lds, unsigned grid, hipStream_t st) {
-  return dk == 64 ? launch_fwd<4, NT>(a, lds, grid, st) : dk == 32 ? launch_fwd<2, NT>(a, lds, grid, st)
-                                                                   : launch_fwd<1, NT>(a, lds, grid, st);
+int launch_fwd_dk(int dk, const AttnArgs& a, size_t lds, hipStream_t st) {
+  return dk == 64 ? launch_fwd<4, NT>(a, lds, st) : dk == 32 ? launch_fwd<2, NT>(a, lds, st) : launch_fwd<1, NT>(a, lds, st);
 }
 template <int NT>
 int launch_bwd_dk(int dk, const AttnArgs& a, size_t lds, unsigned grid, hipStream_t st) {
@@ -706,25 +801,21 @@ extern "C" int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t
                             uint32_t site, void* stream) {
   int rc = check_common("attn_fwd", q, ldq, k, ldk, v, ldv, mbits, mb_sb, mb_sq, B, H, Lq, Lk, dk, p);
   if (rc) return rc;
-  GCT_CHECK_ARG(o && lse && ldo % 4 == 0 && gct_aligned16(o), "attn_fwd: bad output");
+  GCT_CHECK_ARG(o && lse && ldo % 4 == 0 && gct_aligned16(o) && (int64_t)Lq * ldo * 4 < (1ll << 31), "attn_fwd: bad output");
   if (B == 0) return GCT_OK;
   AttnArgs a = {};
-  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
-  a.mbits = mbits; a.mb_sb = mb_sb; a.mb_sq = mb_sq;
-  a.o = o; a.ldo = ldo; a.lse = lse; a.probs = probs;
+  a.q = q; a.k = k; a.v = v; a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv;
+  a.mbits = mbits; a.mb_sb = (int)mb_sb; a.mb_sq = (int)mb_sq;
+  a.o = o; a.ldo = (int)ldo; a.lse = lse; a.probs = probs;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.npairs = B * H; a.scale = scale;
   a.thr = gct_drop_threshold(p); a.keep_scale = 1.0f / (1.0f - p); a.rng = gct_rng_make(seed, site);
   const int LQP = (Lq + 15) & ~15, LKP = (Lk + 15) & ~15, SD = dk + 4;
-  const int nt = (LQP > LKP ? LQP : LKP) / 16;
+  const int nt = LKP / 16;                      // query tiles beyond the wave count are looped
   const size_t lds = (size_t)(2 * LKP) * SD * 4;
   GCT_CHECK_ARG(lds <= 160 * 1024, "attn_fwd: needs %zu B of LDS", lds);
-  // persistent workgroups: as many as are resident together (2 per CU at L <= 128, 1 beyond)
-  const int per_cu = lds <= 76 * 1024 ? 2 : 1;
-  const int64_t want = (int64_t)num_cus() * per_cu;
-  const unsigned grid = (unsigned)(a.npairs < want ? a.npairs : want);
   hipStream_t st = (hipStream_t)stream;
-  rc = nt <= 6 ? launch_fwd_dk<6>(dk, a, lds, grid, st) : nt <= 8 ? launch_fwd_dk<8>(dk, a, lds, grid, st)
-                                                                  : launch_fwd_dk<13>(dk, a, lds, grid, st);
+  rc = nt <= 6 ? launch_fwd_dk<6>(dk, a, lds, st) : nt <= 8 ? launch_fwd_dk<8>(dk, a, lds, st)
+                                                            : launch_fwd_dk<13>(dk, a, lds, st);
   if (rc) return rc;
   GCT_LAUNCH_CHECK("attn_fwd");
   return GCT_OK;
@@ -744,12 +835,14 @@ extern "C" int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t
                     gct_aligned16(o) && gct_aligned16(dout) && gct_aligned16(dq) &&
                     gct_aligned16(dk_) && gct_aligned16(dv),
                 "attn_bwd: buffers must be 16-B aligned with ld %% 4 == 0");
+  GCT_CHECK_ARG((int64_t)Lq * (ldo > lddq ? ldo : lddq) * 4 < (1ll << 31) && (int64_t)Lk * (lddk > lddv ? lddk : lddv) * 4 < (1ll << 31),
+                "attn_bwd: one (batch) slice exceeds 2 GiB");
   if (B == 0) return GCT_OK;
   AttnArgs a = {};
-  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
-  a.mbits = mbits; a.mb_sb = mb_sb; a.mb_sq = mb_sq;
-  a.o_in = o; a.dout = dout; a.ldo = ldo; a.lse_in = lse;
-  a.dq = dq; a.dk = dk_; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  a.q = q; a.k = k; a.v = v; a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv;
+  a.mbits = mbits; a.mb_sb = (int)mb_sb; a.mb_sq = (int)mb_sq;
+  a.o_in = o; a.dout = dout; a.ldo = (int)ldo; a.lse_in = lse;
+  a.dq = dq; a.dk = dk_; a.dv = dv; a.lddq = (int)lddq; a.lddk = (int)lddk; a.lddv = (int)lddv;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.npairs = B * H; a.scale = scale;
   a.thr = gct_drop_threshold(p); a.keep_scale = 1.0f / (1.0f - p); a.rng = gct_rng_make(seed, site);
   const int LQP = (Lq + 15) & ~15, LKP = (Lk + 15) & ~15, SD = dk + 4;

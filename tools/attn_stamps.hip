@@ -1,73 +1,47 @@
-// Diagnostic: s_memtime stamps of attn_fwd_kernel (B=512,H=8,L=80,dk=64, key-padding mask).
+// Diagnostic: s_memtime stamps of attn_fwd_kernel (B=512,H=8,L=80,dk=64, key-padding mask, ragged lengths).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DGCT_STAMPS tools/attn_stamps.hip -o tools/_build/attn_stamps
 #include "../gct_plus_amd/csrc/capi.hip"
 #include "../gct_plus_amd/csrc/attention.hip"
 #include <vector>
 int main() {
   const int B = 512, H = 8, L = 80, dk = 64, d = H * dk;
-  float *qkv, *o, *lse; uint8_t* mask; unsigned long long* st;
+  float *qkv, *o, *lse; uint8_t* mask; uint32_t* bits; unsigned long long* st;
   hipMalloc(&qkv, (size_t)B * L * 3 * d * 4); hipMalloc(&o, (size_t)B * L * d * 4); hipMalloc(&lse, B * H * L * 4);
-  hipMalloc(&mask, B * L); hipMalloc(&st, 64 * 12 * 8 * 8);
+  hipMalloc(&mask, B * L); hipMalloc(&bits, B * 8 * 4); hipMalloc(&st, 64 * 6 * 8 * 8);
   std::vector<float> h((size_t)B * L * 3 * d);
   for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
   hipMemcpy(qkv, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-  std::vector<uint8_t> m(B * L);
-  for (int b = 0; b < B; ++b) for (int j = 0; j < L; ++j) m[b * L + j] = j < 20 + (b * 7) % 60;
-  hipMemcpy(mask, m.data(), m.size(), hipMemcpyHostToDevice);
-  for (int variant = 0; variant < 2; ++variant) {
-    AttnArgs a = {};
-    a.q = qkv; a.k = qkv + d; a.v = qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
-    a.mask = mask; a.mask_sb = L; a.mask_sq = 0; a.o = o; a.ldo = d; a.lse = lse;
-    a.B = B; a.H = H; a.Lq = L; a.Lk = L; a.scale = 0.125f;
-    const float p = variant ? 0.1f : 0.0f;
-    a.thr = gct_drop_threshold(p); a.keep_scale = 1.f / (1.f - p); a.rng = gct_rng_make(1, 1);
-    a.stamps = st;
-    const size_t lds = (size_t)(160) * 68 * 4 + 80 * 80 + MAPS_BYTES;
-    hipFuncSetAttribute((const void*)attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    for (int rep = 0; rep < 3; ++rep) {
-      hipMemset(st, 0, 64 * 8 * 8 * 8);
-      hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(B * H), dim3(FWD_THREADS), lds, 0, a);
-      hipDeviceSynchronize();
-    }
-    std::vector<unsigned long long> hs(64 * 8 * 8);
-    hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
-    const char* nm[6] = {"stage qkv", "flags+sync", "maps+sync", "S=KQ^T", "softmax", "PV+store"};
-    printf("dropout p=%.1f\n", p);
-    for (int w = 0; w < 8; w += 7) {
-      double seg[8] = {0};
-      for (int b = 0; b < 64; ++b) for (int i = 0; i < 8; ++i) seg[i] += (double)hs[(b * 8 + w) * 8 + i] / 64;
-      double tot = 0; for (int i = 0; i < 6; ++i) tot += seg[i];
-      printf(" wave %d lifetime %.0f cycles:", w, tot);
-      for (int i = 0; i < 6; ++i) printf("  %s %.0f", nm[i], seg[i]);
-      printf("\n");
-    }
-  }
-  {  // backward
-    float *dqkv, *dout; hipMalloc(&dqkv, (size_t)B * L * 3 * d * 4); hipMalloc(&dout, (size_t)B * L * d * 4);
-    hipMemcpy(dout, h.data(), (size_t)B * L * d * 4, hipMemcpyHostToDevice);
-    AttnArgs a = {};
-    a.q = qkv; a.k = qkv + d; a.v = qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
-    a.mask = mask; a.mask_sb = L; a.mask_sq = 0; a.o_in = o; a.dout = dout; a.ldo = d; a.lse_in = lse;
-    a.dq = dqkv; a.dk = dqkv + d; a.dv = dqkv + 2 * d; a.lddq = a.lddk = a.lddv = 3 * d;
-    a.B = B; a.H = H; a.Lq = L; a.Lk = L; a.scale = 0.125f;
-    a.thr = gct_drop_threshold(0.1f); a.keep_scale = 1.f / 0.9f; a.rng = gct_rng_make(1, 1);
-    a.stamps = st;
-    const size_t lds = (size_t)(320) * 68 * 4 + 80 * 8 + 80 * 80 + MAPS_BYTES;
-    hipFuncSetAttribute((const void*)attn_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    for (int rep = 0; rep < 3; ++rep) {
-      hipMemset(st, 0, 64 * 12 * 8 * 8);
-      hipLaunchKernelGGL(attn_bwd_kernel<4>, dim3(B * H), dim3(BWD_THREADS), lds, 0, a);
-      hipDeviceSynchronize();
-    }
-    std::vector<unsigned long long> hs(64 * 12 * 8);
-    hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
-    const char* nm[4] = {"stage+flags", "delta+sync", "maps+sync", "unit"};
-    for (int w = 0; w < 12; w += 5) {
-      double seg[8] = {0};
-      for (int b = 0; b < 64; ++b) for (int i = 0; i < 8; ++i) seg[i] += (double)hs[(b * 12 + w) * 8 + i] / 64;
-      printf(" bwd wave %d:", w);
-      for (int i = 0; i < 4; ++i) printf("  %s %.0f", nm[i], seg[i]);
-      printf("\n");
+  for (int fixed = 0; fixed < 2; ++fixed) {
+    std::vector<uint8_t> m(B * L);
+    for (int b = 0; b < B; ++b) for (int j = 0; j < L; ++j) m[b * L + j] = fixed ? 1 : (j < 20 + (b * 7) % 40);
+    hipMemcpy(mask, m.data(), m.size(), hipMemcpyHostToDevice);
+    gct_attn_mask_pack(mask, L, 0, B, L, L, bits, nullptr);
+    for (int variant = 0; variant < 2; ++variant) {
+      AttnArgs a = {};
+      a.q = qkv; a.k = qkv + d; a.v = qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
+      a.mbits = bits; a.mb_sb = 8; a.mb_sq = 0; a.o = o; a.ldo = d; a.lse = lse;
+      a.B = B; a.H = H; a.Lq = L; a.Lk = L; a.npairs = B * H; a.scale = 0.125f;
+      const float p = variant ? 0.1f : 0.0f;
+      a.thr = gct_drop_threshold(p); a.keep_scale = 1.f / (1.f - p); a.rng = gct_rng_make(1, 1);
+      a.stamps = st;
+      const size_t lds = (size_t)(160) * 68 * 4;
+      for (int rep = 0; rep < 3; ++rep) {
+        hipMemset(st, 0, 64 * 6 * 8 * 8);
+        hipLaunchKernelGGL((attn_fwd_kernel<4, 6, true, 3>), dim3(512), dim3(ATT_THREADS), lds, 0, a);
+        hipDeviceSynchronize();
+      }
+      std::vector<unsigned long long> hs(64 * 6 * 8);
+      hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
+      const char* nm[6] = {"seam", "wait+lds store", "barrier1", "prefetch issue", "compute", "barrier2"};
+      printf("fixed=%d dropout p=%.1f (cycles per wave over 8 pairs)\n", fixed, p);
+      for (int w = 0; w < 6; ++w) {
+        double seg[8] = {0};
+        for (int b = 0; b < 64; ++b) for (int i = 0; i < 8; ++i) seg[i] += (double)hs[(b * 6 + w) * 8 + i] / 64;
+        double tot = 0; for (int i = 0; i < 6; ++i) tot += seg[i];
+        printf(" wave %d total %.0f:", w, tot);
+        for (int i = 0; i < 6; ++i) printf("  %s %.0f", nm[i], seg[i]);
+        printf("\n");
+      }
     }
   }
   return 0;

@@ -61,8 +61,12 @@ def gemm_suite(reps, only=None):
 
 def attn_suite(reps, fixed=False):
     dev = "cuda"
-    for name, B, H, Lq, Lk, dk, causal in (("enc", 512, 8, 80, 80, 64, False), ("dec", 512, 8, 81, 81, 64, True),
-                                           ("cross", 512, 8, 81, 80, 64, False)):
+    shapes = [("enc", 512, 8, 80, 80, 64, False), ("dec", 512, 8, 81, 81, 64, True), ("cross", 512, 8, 81, 80, 64, False)]
+    if os.environ.get("ATTN_LAYOUT_PROBE"):
+        # same work per (batch, head) pair, but every pair's q / k / v slice is CONTIGUOUS (H = 1): what the
+        # head-sliced 256-B-per-row access of the [M, 3d] projection buffer costs
+        shapes = [("enc", 512, 8, 80, 80, 64, False), ("encH1", 4096, 1, 80, 80, 64, False)]
+    for name, B, H, Lq, Lk, dk, causal in shapes:
         d = H * dk
         qkv = torch.randn(B * max(Lq, Lk), 3 * d, device=dev)
         # MOSES-like ragged lengths: l ~ N(35,8) clipped to [15, L]
@@ -76,16 +80,21 @@ def attn_suite(reps, fixed=False):
         else:
             mask = pad.to(torch.uint8).contiguous()
         q, k, v = qkv, qkv[:, d:], qkv[:, 2 * d:]
+        ld = 3 * d
+        if name == "encH1":
+            q, k, v = (torch.randn(B * Lq, d, device=dev) for _ in range(3))
+            ld = d
         mask = ops.pack_mask(mask, B, Lq, Lk)        # packed once per forward in the engine, not per call
-        o, lse, _ = ops.attn_fwd(q, k, v, 3 * d, 3 * d, 3 * d, mask, B, H, Lq, Lk, dk, 0.1, 1, 1)
+        o, lse, _ = ops.attn_fwd(q, k, v, ld, ld, ld, mask, B, H, Lq, Lk, dk, 0.1, 1, 1)
         do = torch.randn_like(o)
         dqkv = torch.empty_like(qkv)
+        dq_, dk__, dv_ = (dqkv, dqkv[:, d:], dqkv[:, 2 * d:]) if name != "encH1" else (torch.empty_like(q), torch.empty_like(k), torch.empty_like(v))
         fl = 4.0 * B * H * Lq * Lk * dk
-        med, best = timeit(lambda: ops.attn_fwd(q, k, v, 3 * d, 3 * d, 3 * d, mask, B, H, Lq, Lk, dk, 0.1, 1, 1), reps)
+        med, best = timeit(lambda: ops.attn_fwd(q, k, v, ld, ld, ld, mask, B, H, Lq, Lk, dk, 0.1, 1, 1), reps)
         gb = 4.0 * B * max(Lq, Lk) * d * 4
         print(f"attn {name:5s} fwd{' fixed' if fixed else ''}: {med*1e6:8.1f} us  {fl/med/1e12:6.2f} TF  {gb/med/1e9:7.0f} GB/s", flush=True)
-        med, best = timeit(lambda: ops.attn_bwd(q, k, v, 3 * d, 3 * d, 3 * d, mask, o, do, lse, dqkv, dqkv[:, d:],
-                                                dqkv[:, 2 * d:], 3 * d, 3 * d, 3 * d, B, H, Lq, Lk, dk, 0.1, 1, 1), reps)
+        med, best = timeit(lambda: ops.attn_bwd(q, k, v, ld, ld, ld, mask, o, do, lse, dq_, dk__, dv_, ld, ld, ld,
+                                                B, H, Lq, Lk, dk, 0.1, 1, 1), reps)
         print(f"attn {name:5s} bwd{' fixed' if fixed else ''}: {med*1e6:8.1f} us  {2.5*fl/med/1e12:6.2f} TF  {2*gb/med/1e9:7.0f} GB/s", flush=True)
 
 
