@@ -21,7 +21,7 @@ SIGNATURES = {
     "gct_rowred_ws_bytes": (I64, [I64, I64]),
     "gct_embed_ws_bytes": (I64, [I32, I32, I32, I32]),
     "gct_norm_fwd": (I32, [P, P, P, P, P, P, I64, I32, F32, P]),
-    "gct_norm_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, I64, I32, F32, P]),
+    "gct_norm_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, I64, I32, F32, P, I64, P]),
     "gct_embed_pe_fwd": (I32, [P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, U64, U32, P]),
     "gct_embed_pe_bwd": (I32, [P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, U64, U32, P]),
     "gct_linear_fwd": (I32, [P, I64, I64, I32, P, P, P, I64, P, P, P, I32, I32, P, P, P, I64,
@@ -32,7 +32,7 @@ SIGNATURES = {
     "gct_linear_fwd_p": (I32, [P, I64, I64, I32, P, P, P, I64, P, I64, P, P, P, I32, I32, P, P, P, I64,
                                I32, P, P, F32, U64, U32, P, P]),
     "gct_linear_dgrad_p": (I32, [P, P, P, I64, I64, I32, I32, P, P, P, I64, P, I64, I32, P, I64, I32, P,
-                                 F32, U64, U32, P, P]),
+                                 F32, U64, U32, P, P, P]),
     "gct_linear_dgrad_ws_bytes": (I64, [I64, I32, I32]),
     "gct_gemm_set_mode": (I32, [I32]),
     "gct_gemm_get_mode": (I32, []),
@@ -44,14 +44,16 @@ SIGNATURES = {
     "gct_linear_wgrad": (I32, [P, P, P, I64, I64, I32, I32, P, I64, I32, P, P, P, I64, P, P, P,
                                P, P]),
     "gct_nonzero_row_tiles": (I32, [P, I64, I64, I32, P, P, P, P]),
-    "gct_live_rows": (I32, [P, I64, I32, I32, I32, P, I64, I64, P, P, P, P, P, P, P, P, P]),
+    "gct_live_rows": (I32, [P, I64, I32, I32, I32, P, I64, I64, P, P, P, P, P, P, P, P, P, P]),
+    "gct_gather_quads": (I32, [P, I64, I64, P, I64, I32, P, I64, P]),
+    "gct_scatter_quads": (I32, [P, I64, P, I64, I32, P, I64, I64, P]),
     "gct_linear_wgrad_kt": (I32, [P, P, P, I64, I64, I32, I32, P, I64, I32, P, P, P, I64, P, P, P,
                                   P, P, P, P]),
-    "gct_dropout_bwd": (I32, [P, P, I64, I32, F32, U64, U32, P]),
+    "gct_dropout_bwd": (I32, [P, P, I64, I32, F32, U64, U32, P, P]),
     "gct_attn_fwd": (I32, [P, I64, P, I64, P, I64, P, I64, I64, P, I64, P, P, I32, I32, I32, I32,
                            I32, F32, F32, U64, U32, P]),
     "gct_attn_bwd": (I32, [P, I64, P, I64, P, I64, P, I64, I64, P, P, I64, P, P, I64, P, I64,
-                           P, I64, I32, I32, I32, I32, I32, F32, F32, U64, U32, P]),
+                           P, I64, I32, I32, I32, I32, I32, F32, F32, U64, U32, P, P, I32, P]),
     "gct_attn_mask_pack": (I32, [P, I64, I64, I32, I32, I32, P, P]),
     "gct_reparam_fwd": (I32, [P, P, P, P, P, I64, U64, U32, P]),
     "gct_reparam_bwd": (I32, [P, P, P, P, P, P, P, I64, P]),
@@ -71,7 +73,7 @@ SIGNATURES = {
     "gct_add": (I32, [P, P, P, I64, P]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 

@@ -57,6 +57,10 @@ struct AttnArgs {
   const float *o_in, *dout, *lse_in;
   float *dq, *dk, *dv;
   int lddq, lddk, lddv;
+  // compacted decoder backward (csrc/liverows.hip): dout / dq rows of sample b start at cstart[b] and only the first
+  // nlive[b] query rows exist; kv_compact: dk / dv (self-attention) live in the same compact rows
+  const int32_t *cstart, *nlive;
+  int kv_compact;
   int B, H, Lq, Lk, npairs;
   float scale, keep_scale;
   uint32_t thr;
@@ -122,6 +126,12 @@ struct Stage {
     for (int it = 0; it < ITERS; ++it)
       v[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + o.off[it]);
   }
+  __device__ __forceinline__ void load_rows(const float* src, int ld, int64_t row0, int h, const StageOff<DK, NT>& o) {
+    const float* base = src + row0 * ld + h * DK;                 // wave-uniform
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it)
+      v[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + o.off[it]);
+  }
   __device__ __forceinline__ void store(float* dst, int L, int LP, int tid) const {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
@@ -153,6 +163,15 @@ __device__ __forceinline__ void row_frag_global(float4 (&f)[NDT], const float* s
   const int rr = row < L ? row : L - 1;
   const char* base = reinterpret_cast<const char*>(src + (int64_t)b * L * ld + h * 16 * NDT);   // wave-uniform
   const uint32_t off = (uint32_t)((rr * ld + g * 4 * NDT) * 4);                                   // per lane
+#pragma unroll
+  for (int j = 0; j < NDT; ++j) f[j] = *reinterpret_cast<const float4*>(base + off + 16 * j);
+}
+template <int NDT>
+__device__ __forceinline__ void row_frag_rows(float4 (&f)[NDT], const float* src, int ld, int64_t row0, int h, int L,
+                                              int row, int g) {
+  const int rr = row < L ? row : (L > 0 ? L - 1 : 0);
+  const char* base = reinterpret_cast<const char*>(src + row0 * ld + h * 16 * NDT);              // wave-uniform
+  const uint32_t off = (uint32_t)((rr * ld + g * 4 * NDT) * 4);
 #pragma unroll
   for (int j = 0; j < NDT; ++j) f[j] = *reinterpret_cast<const float4*>(base + off + 16 * j);
 }
@@ -439,13 +458,17 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
   for (int pair = blockIdx.x; pair < a.npairs; pair += (int)gridDim.x) {
     const int b = pair / a.H, h = pair - b * a.H;
     const int64_t lrow0 = ((int64_t)b * a.H + h) * a.Lq;
+    const int Lq_e = a.nlive ? a.nlive[b] : a.Lq;                               // query rows that exist in dout / dq
+    const int64_t drow0 = a.cstart ? (int64_t)a.cstart[b] : (int64_t)b * a.Lq;  // row of (b, 0) in dout / dq
+    const int Lk_e = a.kv_compact ? Lq_e : a.Lk;                                // key rows that exist in dk / dv
+    const int64_t krow0 = a.kv_compact ? drow0 : (int64_t)b * a.Lk;
     // ---------------------------------------------------------------- phase A: K, V in LDS -> dQ
     // every global load of this phase is issued up front: this wave's Q / dO / O rows and lse ride along with the
     // K / V staging loads, so the MFMAs below start with everything on chip
     const int q0 = 16 * wave + c16;
     float4 bq[NDT], bd[NDT], bo[NDT];
     row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, q0, g);
-    row_frag_global<NDT>(bd, a.dout, a.ldo, b, h, a.Lq, q0, g);
+    row_frag_rows<NDT>(bd, a.dout, a.ldo, drow0, h, Lq_e, q0, g);
     row_frag_global<NDT>(bo, a.o_in, a.ldo, b, h, a.Lq, q0, g);
     float lse0 = a.lse_in[lrow0 + (q0 < a.Lq ? q0 : a.Lq - 1)];
     {
@@ -474,10 +497,10 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
     bool tile_live = false;
     for (int u = wave; u < nqt; u += NW) {
       const int q = 16 * u + c16;
-      const bool real = q < a.Lq;
+      const bool real = q < Lq_e;
       if (u != wave) {                   // more query tiles than waves (L > 96): load in place
         row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, q, g);
-        row_frag_global<NDT>(bd, a.dout, a.ldo, b, h, a.Lq, q, g);
+        row_frag_rows<NDT>(bd, a.dout, a.ldo, drow0, h, Lq_e, q, g);
         row_frag_global<NDT>(bo, a.o_in, a.ldo, b, h, a.Lq, q, g);
         lse0 = a.lse_in[lrow0 + (real ? q : a.Lq - 1)];
       }
@@ -503,7 +526,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
       tile_live = __any(nz);
       if (!tile_live) {                       // all 16 gradient rows are zero: dQ rows = 0, nothing else
         if (real) {
-          char* dbase = reinterpret_cast<char*>(a.dq + (int64_t)b * a.Lq * a.lddq + h * DK);
+          char* dbase = reinterpret_cast<char*>(a.dq + drow0 * a.lddq + h * DK);
           const uint32_t doff = (uint32_t)((q * a.lddq + 4 * g) * 4);
 #pragma unroll
           for (int dt = 0; dt < NDT; ++dt) *reinterpret_cast<float4*>(dbase + doff + 64 * dt) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -570,7 +593,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
           }
         }
       if (real) {
-        char* dbase = reinterpret_cast<char*>(a.dq + (int64_t)b * a.Lq * a.lddq + h * DK);
+        char* dbase = reinterpret_cast<char*>(a.dq + drow0 * a.lddq + h * DK);
         const uint32_t doff = (uint32_t)((q * a.lddq + 4 * g) * 4);
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
@@ -591,7 +614,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
       // layout row_frag reads back (dead tiles are never read by phase B; rows beyond Lq are zeroed)
       if (wave < nqt && tile_live) {
         const int q = 16 * wave + c16;
-        const bool real = q < a.Lq;
+        const bool real = q < Lq_e;
 #pragma unroll
         for (int j = 0; j < NDT; ++j) {
           *reinterpret_cast<float4*>(R0 + q * SD + g * 4 * NDT + 4 * j) = real ? bq[j] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -604,15 +627,16 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
       qo.init(a.ldq, a.Lq, tid);
       dof.init(a.ldo, a.Lq, tid);
       sq.load(a.q, a.ldq, b, h, a.Lq, qo);           // second read of this pair's Q / dO: L2
-      sd.load(a.dout, a.ldo, b, h, a.Lq, dof);
+      sd.load_rows(a.dout, a.ldo, drow0, h, dof);    // (rows beyond Lq_e belong to other samples: zeroed by store)
       row_frag_global<NDT>(bk, a.k, a.ldk, b, h, a.Lk, 16 * wave + c16, g);
       row_frag_global<NDT>(bv, a.v, a.ldv, b, h, a.Lk, 16 * wave + c16, g);
-      sq.store(R0, a.Lq, LQP, tid);
-      sd.store(R1, a.Lq, LQP, tid);
+      sq.store(R0, Lq_e, LQP, tid);
+      sd.store(R1, Lq_e, LQP, tid);
     }
     __syncthreads();
     for (int t = wave; t < nkt; t += NW) {
       const int k = 16 * t + c16;
+      if (16 * t >= Lk_e) continue;        // compact self-attention: dead keys have no row (and no gradient)
       if (t != wave) {
         row_frag_global<NDT>(bk, a.k, a.ldk, b, h, a.Lk, k, g);
         row_frag_global<NDT>(bv, a.v, a.ldv, b, h, a.Lk, k, g);
@@ -668,9 +692,9 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
           }
         }
       }
-      if (k < a.Lk) {
-        char* vbase = reinterpret_cast<char*>(a.dv + (int64_t)b * a.Lk * a.lddv + h * DK);
-        char* kbase = reinterpret_cast<char*>(a.dk + (int64_t)b * a.Lk * a.lddk + h * DK);
+      if (k < Lk_e) {
+        char* vbase = reinterpret_cast<char*>(a.dv + krow0 * a.lddv + h * DK);
+        char* kbase = reinterpret_cast<char*>(a.dk + krow0 * a.lddk + h * DK);
         const uint32_t voff = (uint32_t)((k * a.lddv + 4 * g) * 4), koff = (uint32_t)((k * a.lddk + 4 * g) * 4);
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
@@ -827,7 +851,7 @@ extern "C" int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t
                             const float* lse, float* dq, int64_t lddq, float* dk_,
                             int64_t lddk, float* dv, int64_t lddv, int B, int H, int Lq, int Lk,
                             int dk, float scale, float p, uint64_t seed, uint32_t site,
-                            void* stream) {
+                            const int32_t* cstart, const int32_t* nlive, int kv_compact, void* stream) {
   int rc = check_common("attn_bwd", q, ldq, k, ldk, v, ldv, mbits, mb_sb, mb_sq, B, H, Lq, Lk, dk, p);
   if (rc) return rc;
   GCT_CHECK_ARG(o && dout && lse && dq && dk_ && dv, "attn_bwd: null pointer");
@@ -843,6 +867,9 @@ extern "C" int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t
   a.mbits = mbits; a.mb_sb = (int)mb_sb; a.mb_sq = (int)mb_sq;
   a.o_in = o; a.dout = dout; a.ldo = (int)ldo; a.lse_in = lse;
   a.dq = dq; a.dk = dk_; a.dv = dv; a.lddq = (int)lddq; a.lddk = (int)lddk; a.lddv = (int)lddv;
+  GCT_CHECK_ARG((cstart == nullptr) == (nlive == nullptr) && (!kv_compact || (cstart && Lq == Lk)),
+                "attn_bwd: cstart / nlive go together; kv_compact needs them and Lq == Lk");
+  a.cstart = cstart; a.nlive = nlive; a.kv_compact = kv_compact;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.npairs = B * H; a.scale = scale;
   a.thr = gct_drop_threshold(p); a.keep_scale = 1.0f / (1.0f - p); a.rng = gct_rng_make(seed, site);
   const int LQP = (Lq + 15) & ~15, LKP = (Lk + 15) & ~15, SD = dk + 4;

@@ -65,6 +65,8 @@ struct GemmArgs {
   float* bias_slab;  // wgrad fast path: per-split column sums of dY, [nsplit][M] (nullptr: off)
   int stagger;       // s_sleep(127) repeats for the second resident workgroup of each CU
   int64_t row_base;  // rows in front of this launch's row 0 (a launch on a row range keeps the dropout coordinates)
+  const int32_t* quad_map;  // rows are a quad compaction (csrc/liverows.hip): dropout coordinates of compact quad q are
+                            // those of original quad quad_map[q] (nullptr: identity)
   const int32_t* kt_list;   // bf16x6 wgrad: ascending 32-row K-tile indices to reduce over (nullptr: all)
   const int32_t* kt_count;  // device scalar: entries of kt_list
   const uint16_t* bp0;  // bf16x6 kernels: pre-split planes of the B operand (same element offsets as b)
@@ -75,6 +77,16 @@ struct GemmArgs {
 };
 
 enum { EPI_SLAB = 32, EPI_D0 = 16 };
+
+// quad (row >> 2) whose Philox stream covers `row` of this launch
+__device__ __forceinline__ uint32_t drop_quad(const GemmArgs& g, int64_t row) {
+  int64_t q = (row + g.row_base) >> 2;
+  if (g.quad_map) {
+    const int v = g.quad_map[q];
+    q = v < 0 ? 0 : v;                 // padding quads: their rows are zero whatever the mask says
+  }
+  return (uint32_t)q;
+}
 
 #ifdef GCT_STAMPS
 #define STAMP(i)                                                                       \
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
         const bool need_rng = g.thr != 0u && (g.epi == GCT_EPI_GELU_DROP ||
                                               g.epi == GCT_EPI_DROP_RESID ||
                                               g.epi == EPI_D0 + GCT_DEPI_GELU_BWD);
-        if (need_rng) bits = gct_drop_bits(g.rng, (uint32_t)((row_base + g.row_base) >> 2), (uint32_t)col);
+        if (need_rng) bits = gct_drop_bits(g.rng, drop_quad(g, row_base), (uint32_t)col);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int64_t row = row_base + e;
@@ -471,7 +483,7 @@ struct FastEpi {
     if (rng) {
 #pragma unroll
       for (int cp = 0; cp < 2; ++cp)
-        bits[cp] = gct_drop_bits(g.rng, (uint32_t)((row0 + g.row_base) >> 2), (uint32_t)(col0 + 2 * cp));
+        bits[cp] = gct_drop_bits(g.rng, drop_quad(g, row0), (uint32_t)(col0 + 2 * cp));
     }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -1274,9 +1286,11 @@ static int linear_dgrad_impl(const float* dy0, const float* dy1, const float* dy
                              int64_t M, int nseg, int nper, const float* w0, const float* w1,
                              const float* w2, int64_t ldw, int K, float* dx, int64_t lddx,
                              int depi, const float* pre, float p, uint64_t seed, uint32_t site,
-                             void* stream, const uint16_t* wp0, int64_t pstride, float* ws) {
+                             void* stream, const uint16_t* wp0, int64_t pstride, float* ws,
+                             const int32_t* quad_map = nullptr) {
   GCT_CHECK_ARG(dy0 && w0 && dx && M >= 0 && K > 0 && nseg >= 1 && nseg <= 3 && nper > 0,
                 "linear_dgrad: bad args");
+  GCT_CHECK_ARG(!quad_map || M % 4 == 0, "linear_dgrad: compacted rows come in quads");
   GCT_CHECK_ARG(nseg < 2 || (w1 && dy1), "linear_dgrad: missing segment 1");
   GCT_CHECK_ARG(nseg < 3 || (w2 && dy2), "linear_dgrad: missing segment 2");
   GCT_CHECK_ARG(depi != GCT_DEPI_GELU_BWD || pre, "linear_dgrad: GELU bwd needs pre");
@@ -1290,6 +1304,7 @@ static int linear_dgrad_impl(const float* dy0, const float* dy1, const float* dy
   g.pre_in = pre;
   g.thr = gct_drop_threshold(p); g.keep_scale = 1.0f / (1.0f - p); g.rng = gct_rng_make(seed, site);
   g.bp0 = wp0; g.bp_stride = pstride;
+  g.quad_map = quad_map;
   const bool vec = al16(dy0) && al16(dy1) && al16(dy2) && al16(w0) && al16(w1) && al16(w2) &&
                    (lddy % 4 == 0) && (ldw % 4 == 0) && (nper % 4 == 0) && (K % 4 == 0);
   return launch<true, false>(g, vec, (hipStream_t)stream, ws, ws ? INT64_MAX : 0);   // ws sized by gct_linear_dgrad_ws_bytes
@@ -1309,9 +1324,9 @@ extern "C" int gct_linear_dgrad_p(const float* dy0, const float* dy1, const floa
                                   const float* w2, int64_t ldw, const uint16_t* wp0,
                                   int64_t plane_stride, int K, float* dx, int64_t lddx, int depi,
                                   const float* pre, float p, uint64_t seed, uint32_t site,
-                                  float* ws, void* stream) {
+                                  float* ws, const int32_t* quad_map, void* stream) {
   return linear_dgrad_impl(dy0, dy1, dy2, lddy, M, nseg, nper, w0, w1, w2, ldw, K, dx, lddx, depi, pre,
-                           p, seed, site, stream, wp0, plane_stride, ws);
+                           p, seed, site, stream, wp0, plane_stride, ws, quad_map);
 }
 
 static int linear_wgrad_impl(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,

@@ -15,9 +15,17 @@
 //                   or a live row whose mask row is all zero next to any dead row     (uniform attention over ALL keys)
 //   non-prefix    = exists (b,t):   !live[b,t] && live[b,t+1]                        (live rows are not 0..n_b-1)
 //
-// gct_live_rows also emits what the shortcuts consume: per-sample counts and offsets, the ascending list of live
-// row ids padded to a multiple of 128 with -1, and the list of 32-row token tiles that hold a live row (ALL tiles
-// when the check fails, so a consumer of the tile list needs no host round trip to stay exact).
+// gct_live_rows also emits what the shortcuts consume:
+//   * the list of 32-row token tiles that hold a live row (ALL tiles when the check fails, so a consumer of the
+//     tile list needs no host round trip to stay exact);
+//   * the COMPACTION MAP of the decoder backward.  Rows are compacted in aligned groups of 4 ("quads": rows 4q..4q+3
+//     of the [B*T] row space), because every dropout site draws one Philox value per 4 rows x 2 columns -- keeping
+//     quads intact keeps that cost, a kernel only needs the ORIGINAL quad index of each compact quad:
+//        quad_list[i] = original quad of compact quad i (ascending; padded with -1 to a multiple of 32 quads),
+//        compact row 4i + e  <->  original row 4 * quad_list[i] + e,
+//        cstart[b]    = compact row of (b, t = 0); the live rows of a sample are contiguous in both spaces, so
+//                       (b, t) sits at compact row cstart[b] + t for t < n_b when the live rows are the prefix 0..n_b-1.
+//     About 8 % more rows than an exact row compaction at MOSES-like lengths (two partial quads per sample).
 #include "common.h"
 
 namespace {
@@ -91,39 +99,34 @@ __global__ __launch_bounds__(256) void live_flags_kernel(const float* __restrict
   }
 }
 
-// one workgroup: row_off = exclusive scan of n_b; row_list = live row ids ascending, padded with -1 to a
-// multiple of 128; info[4] = padded length
-__global__ __launch_bounds__(1024) void live_lists_kernel(const uint8_t* __restrict__ live, const int32_t* __restrict__ n_b,
-                                                          int B, int T, int32_t* __restrict__ row_off,
-                                                          int32_t* __restrict__ row_list, int32_t* __restrict__ info) {
+// one workgroup: quad_list = live quads ascending, padded with -1 to a multiple of 32; qrank[q] = rank of quad q
+// among the live ones (scratch); cstart[b]; info[4] = compact rows (4 x padded quads), info[5] = live quads
+__global__ __launch_bounds__(1024) void live_quads_kernel(const uint8_t* __restrict__ live, int B, int T,
+                                                          int32_t* __restrict__ quad_list, int32_t* __restrict__ qrank,
+                                                          int32_t* __restrict__ cstart, int32_t* __restrict__ info) {
   __shared__ int wsum[16];
   __shared__ int base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t M = (int64_t)B * T;
+  const int Q = (int)((M + 3) / 4);
   if (tid == 0) base = 0;
   __syncthreads();
-  for (int b0 = 0; b0 < B; b0 += 1024) {
-    const int b = b0 + tid;
-    const int n = b < B ? n_b[b] : 0;
-    int incl = n;                                   // inclusive scan inside the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
+  for (int q0 = 0; q0 < Q; q0 += 1024) {
+    const int q = q0 + tid;
+    int f = 0;
+    if (q < Q)
+      for (int e = 0; e < 4; ++e) {
+        const int64_t r = (int64_t)q * 4 + e;
+        if (r < M && live[r]) f = 1;
+      }
+    const unsigned long long m = __ballot(f);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(m);
     __syncthreads();
     int off = base;
     for (int w = 0; w < wave; ++w) off += wsum[w];
-    off += incl - n;
-    if (b < B) {
-      if (row_off) row_off[b] = off;
-      if (row_list) {
-        int k = off;
-        const uint8_t* lb = live + (int64_t)b * T;
-        for (int t = 0; t < T; ++t)
-          if (lb[t]) row_list[k++] = b * T + t;
-      }
-    }
+    if (q < Q) qrank[q] = off + before;        // for a dead quad: the rank the next live quad will get (unused)
+    if (f) quad_list[off + before] = q;
     __syncthreads();
     if (tid == 0) {
       int tot = 0;
@@ -132,12 +135,46 @@ __global__ __launch_bounds__(1024) void live_lists_kernel(const uint8_t* __restr
     }
     __syncthreads();
   }
-  const int total = base, padded = (total + 127) & ~127;
-  if (row_list)
-    for (int k = total + tid; k < padded; k += 1024) row_list[k] = -1;
+  const int total = base, padded = (total + 31) & ~31;
+  for (int k = total + tid; k < padded; k += 1024) quad_list[k] = -1;
+  __threadfence_block();
+  __syncthreads();
+  for (int b = tid; b < B; b += 1024) {
+    const int64_t r0 = (int64_t)b * T;
+    cstart[b] = 4 * qrank[r0 >> 2] + (int)(r0 & 3);
+  }
   if (tid == 0) {
-    if (row_off) row_off[B] = total;
-    info[4] = padded;
+    info[4] = 4 * padded;
+    info[5] = total;
+  }
+}
+
+// dst[i][:] = src[4 * quad_list[i / 4] + i % 4][:] (zero for padding quads / rows beyond M); float4 columns
+__global__ __launch_bounds__(256) void gather_quads_kernel(const float* __restrict__ src, int64_t ld, int64_t M,
+                                                           const int32_t* __restrict__ quad_list, int64_t nrows,
+                                                           int c4, float* __restrict__ dst, int64_t ldd) {
+  const int64_t total = nrows * c4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / c4;
+    const int c = (int)(i - row * c4);
+    const int q = quad_list[row >> 2];
+    const int64_t r = (int64_t)q * 4 + (row & 3);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q >= 0 && r < M) v = *reinterpret_cast<const float4*>(src + r * ld + c * 4);
+    *reinterpret_cast<float4*>(dst + row * ldd + c * 4) = v;
+  }
+}
+// dst[4 * quad_list[i / 4] + i % 4][:] = src[i][:] for the valid compact rows (dst pre-zeroed by the caller)
+__global__ __launch_bounds__(256) void scatter_quads_kernel(const float* __restrict__ src, int64_t ld,
+                                                            const int32_t* __restrict__ quad_list, int64_t nrows,
+                                                            int c4, float* __restrict__ dst, int64_t ldd, int64_t M) {
+  const int64_t total = nrows * c4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / c4;
+    const int c = (int)(i - row * c4);
+    const int q = quad_list[row >> 2];
+    const int64_t r = (int64_t)q * 4 + (row & 3);
+    if (q >= 0 && r < M) *reinterpret_cast<float4*>(dst + r * ldd + c * 4) = *reinterpret_cast<const float4*>(src + row * ld + c * 4);
   }
 }
 
@@ -191,12 +228,14 @@ __global__ __launch_bounds__(1024) void live_compact_tiles_kernel(const uint8_t*
 
 extern "C" int gct_live_rows(const float* g, int64_t ld, int B, int T, int cols, const uint8_t* mask,
                              int64_t mask_sb, int64_t mask_sq, uint8_t* live, int32_t* n_b, int32_t* info,
-                             int32_t* row_off, int32_t* row_list, int32_t* tile_list, int32_t* tile_count,
-                             uint8_t* tile_flags_ws, void* stream) {
+                             int32_t* cstart, int32_t* quad_list, int32_t* qrank_ws, int32_t* tile_list,
+                             int32_t* tile_count, uint8_t* tile_flags_ws, void* stream) {
   GCT_CHECK_ARG(g && live && n_b && info && B >= 0 && T > 0 && cols > 0 && ld >= cols, "live_rows: bad args");
   GCT_CHECK_ARG(T <= 4096, "live_rows: T = %d unsupported", T);
   GCT_CHECK_ARG((tile_list == nullptr) == (tile_count == nullptr) && (tile_list == nullptr || tile_flags_ws),
                 "live_rows: tile_list / tile_count / tile_flags_ws go together");
+  GCT_CHECK_ARG((cstart == nullptr) == (quad_list == nullptr) && (cstart == nullptr) == (qrank_ws == nullptr),
+                "live_rows: cstart / quad_list / qrank_ws go together");
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(info, 0, 8 * sizeof(int32_t), st);
   if (e != hipSuccess) {
@@ -208,10 +247,10 @@ extern "C" int gct_live_rows(const float* g, int64_t ld, int B, int T, int cols,
                        mask, mask_sb, mask_sq, live, n_b, info);
     GCT_LAUNCH_CHECK("live_flags");
   }
-  if (row_off || row_list) {
-    hipLaunchKernelGGL(live_lists_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)live, (const int32_t*)n_b, B, T,
-                       row_off, row_list, info);
-    GCT_LAUNCH_CHECK("live_lists");
+  if (quad_list) {
+    hipLaunchKernelGGL(live_quads_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)live, B, T, quad_list, qrank_ws,
+                       cstart, info);
+    GCT_LAUNCH_CHECK("live_quads");
   }
   if (tile_list) {
     const int64_t rows = (int64_t)B * T;
@@ -225,5 +264,35 @@ extern "C" int gct_live_rows(const float* g, int64_t ld, int B, int T, int cols,
                        tile_list, tile_count, info);
     GCT_LAUNCH_CHECK("live_compact_tiles");
   }
+  return GCT_OK;
+}
+
+extern "C" int gct_gather_quads(const float* src, int64_t ld, int64_t M, const int32_t* quad_list, int64_t nrows,
+                                int cols, float* dst, int64_t ldd, void* stream) {
+  GCT_CHECK_ARG(src && quad_list && dst && nrows >= 0 && nrows % 4 == 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 &&
+                    ldd % 4 == 0 && gct_aligned16(src) && gct_aligned16(dst),
+                "gather_quads: bad args");
+  if (nrows == 0) return GCT_OK;
+  const int64_t work = nrows * (cols / 4);
+  int64_t grid = (work + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(gather_quads_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, src, ld, M, quad_list,
+                     nrows, cols / 4, dst, ldd);
+  GCT_LAUNCH_CHECK("gather_quads");
+  return GCT_OK;
+}
+
+extern "C" int gct_scatter_quads(const float* src, int64_t ld, const int32_t* quad_list, int64_t nrows, int cols,
+                                 float* dst, int64_t ldd, int64_t M, void* stream) {
+  GCT_CHECK_ARG(src && quad_list && dst && nrows >= 0 && nrows % 4 == 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 &&
+                    ldd % 4 == 0 && gct_aligned16(src) && gct_aligned16(dst),
+                "scatter_quads: bad args");
+  if (nrows == 0) return GCT_OK;
+  const int64_t work = nrows * (cols / 4);
+  int64_t grid = (work + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(scatter_quads_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, src, ld, quad_list,
+                     nrows, cols / 4, dst, ldd, M);
+  GCT_LAUNCH_CHECK("scatter_quads");
   return GCT_OK;
 }

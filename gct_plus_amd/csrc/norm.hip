@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ rstd_in,
                                                        const float* __restrict__ dres, float* dx,
                                                        float* partial, int64_t rows, int d,
-                                                       float eps) {
+                                                       float eps, const int32_t* __restrict__ qmap,
+                                                       int64_t src_rows) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   float4 a[NC], pa[NC], pb[NC];
@@ -96,8 +97,23 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
     pb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += nwaves) {
-    const float mean = mean_in[row], r = rstd_in[row];
-    const float* xr = x + row * d;
+    // qmap: dy / dres / dx are quad-compacted (csrc/liverows.hip); x, mean, rstd stay in the forward's row space
+    int64_t srow = row;
+    if (qmap) {
+      const int q = qmap[row >> 2];
+      srow = (int64_t)q * 4 + (row & 3);
+      if (q < 0 || srow >= src_rows) {            // padding row: its gradient is zero
+        float* dr0 = dx + row * d;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int col = c * 256 + lane * 4;
+          if (col < d) *reinterpret_cast<float4*>(dr0 + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        continue;
+      }
+    }
+    const float mean = mean_in[srow], r = rstd_in[srow];
+    const float* xr = x + srow * d;
     const float* gr = dy + row * d;
     float4 cx[NC], g[NC];
     float s1 = 0.f, s2 = 0.f;
@@ -201,9 +217,10 @@ extern "C" int gct_norm_fwd(const float* x, const float* alpha, const float* bia
 extern "C" int gct_norm_bwd(const float* dy, const float* x, const float* alpha, const float* mean,
                             const float* rstd, const float* dres, float* dx, float* dalpha,
                             float* dbias, float* ws, int64_t rows, int d, float eps,
-                            void* stream) {
+                            const int32_t* quad_map, int64_t src_rows, void* stream) {
   GCT_CHECK_ARG(dy && x && alpha && mean && rstd && dx && dalpha && dbias && ws,
                 "norm_bwd: null pointer");
+  GCT_CHECK_ARG(!quad_map || (rows % 4 == 0 && src_rows > 0), "norm_bwd: compacted rows come in quads");
   GCT_CHECK_ARG(rows >= 0 && d >= 4 && d % 4 == 0 && d <= 256 * MAXC, "norm_bwd: d=%d unsupported", d);
   GCT_CHECK_ARG(gct_aligned16(dy) && gct_aligned16(x) && gct_aligned16(dx) && gct_aligned16(alpha) &&
                     gct_aligned16(ws) && (!dres || gct_aligned16(dres)),
@@ -211,7 +228,7 @@ extern "C" int gct_norm_bwd(const float* dy, const float* x, const float* alpha,
   hipStream_t st = (hipStream_t)stream;
   const int nblk = norm_blocks(rows);
   dim3 grid((unsigned)nblk);
-  NORM_DISPATCH(norm_bwd_kernel, dy, x, alpha, mean, rstd, dres, dx, ws, rows, d, eps);
+  NORM_DISPATCH(norm_bwd_kernel, dy, x, alpha, mean, rstd, dres, dx, ws, rows, d, eps, quad_map, src_rows);
   GCT_LAUNCH_CHECK("norm_bwd");
   // partial layout [blk][2][d]: one slab per block, destinations dalpha | dbias
   return gct_reduce_slabs_seg(ws, nblk, (int64_t)2 * d, dalpha, dbias, nullptr, d, (int64_t)2 * d, st);

@@ -172,16 +172,19 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* src, int64_
 }
 
 // dy[row][col] = keep(row,col) ? dout*scale : 0 ; thread = one column x 4 rows
+// qmap (nullable): the rows are a quad compaction (csrc/liverows.hip) -- compact quad gq carries the dropout
+// coordinates of original quad qmap[gq] (negative: padding, zeros)
 __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* dout, float* dy,
                                                           int64_t rows, int cols, uint32_t thr,
-                                                          float scale, GctRng rng) {
+                                                          float scale, GctRng rng, const int32_t* __restrict__ qmap) {
   const int64_t ngroups = (rows + 3) / 4;
   const int64_t total = ngroups * cols;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t gq = i / cols;
     const int col = (int)(i - gq * cols);
-    const uint4 bits = gct_drop_bits(rng, (uint32_t)gq, (uint32_t)col);
+    const int64_t oq = qmap ? (int64_t)qmap[gq] : gq;
+    const uint4 bits = gct_drop_bits(rng, (uint32_t)(oq < 0 ? 0 : oq), (uint32_t)col);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int64_t row = gq * 4 + e;
@@ -353,12 +356,13 @@ extern "C" int gct_copy_rows(const float* src, int64_t src_rpb, int64_t src_off,
 }
 
 extern "C" int gct_dropout_bwd(const float* dout, float* dy, int64_t rows, int cols, float p,
-                               uint64_t seed, uint32_t site, void* stream) {
+                               uint64_t seed, uint32_t site, const int32_t* quad_map, void* stream) {
   GCT_CHECK_ARG(dout && dy && rows >= 0 && cols > 0 && p >= 0.f && p < 1.f, "dropout_bwd: bad args");
+  GCT_CHECK_ARG(!quad_map || rows % 4 == 0, "dropout_bwd: compacted rows come in quads");
   if (rows == 0) return GCT_OK;
   hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(((rows + 3) / 4) * cols)), dim3(256), 0,
                      (hipStream_t)stream, dout, dy, rows, cols, gct_drop_threshold(p),
-                     1.0f / (1.0f - p), gct_rng_make(seed, site));
+                     1.0f / (1.0f - p), gct_rng_make(seed, site), quad_map);
   GCT_LAUNCH_CHECK("dropout_bwd");
   return GCT_OK;
 }

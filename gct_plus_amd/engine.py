@@ -16,6 +16,7 @@ Reference semantics (file:line relative to /root/reference):
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -24,6 +25,11 @@ from . import ops
 from .flat import HANDED_SLOTS
 
 _SEED = {"base": None, "ctr": 0}
+
+# Compacted decoder backward (decoder_trunk_bwd): on by default, GCT_COMPACT_BWD=0 keeps the dense path.  Taken only
+# when the compact rows are at most this fraction of all rows (the gathers cost ~1 ms per step).
+COMPACT_BWD = os.environ.get("GCT_COMPACT_BWD", "1") != "0"
+COMPACT_MAX_FRACTION = 0.85
 
 
 def next_seed() -> int:
@@ -124,36 +130,47 @@ def mha_fwd(run: Run, m, xq, xkv, B, Lq, Lk, mask_u8, resid, want_probs=False):
 
 
 def mha_bwd(run: Run, m, saved, dy, G: GradSink, dxq_out, depi_q, dxkv_out=None,
-            depi_kv=ops.DEPI_STORE):
+            depi_kv=ops.DEPI_STORE, live=None):
     """dy: gradient w.r.t. the block output (resid + dropout(out(o)) or out(o)).
     Writes dW/db through G, d(xq) into dxq_out (epilogue depi_q) and, for cross-attention,
-    d(xkv) into dxkv_out (epilogue depi_kv).  The identity path to `resid` is the caller's."""
+    d(xkv) into dxkv_out (epilogue depi_kv).  The identity path to `resid` is the caller's.
+    live (ops.LiveRows): the QUERY-side rows (dy, dxq_out) are quad-compacted; saved forward tensors are
+    gathered on the way in, key/value-side gradients of cross-attention stay in the encoder's row space."""
     xq, xkv, qb, kvb, o, lse, mask_u8, B, Lq, Lk, site_p, site_o, fused = saved
     d, H = m.d_model, m.h
     dk = d // H
     Mq, Mk = B * Lq, B * Lk
-    g = ops.dropout_bwd(dy, run.p, run.seed, site_o) if (fused and run.p > 0) else dy
-    ops.linear_wgrad([g], d, o, [G(m.out.weight)], [G(m.out.bias)], kt=run.kt)
-    do = _empty(Mq, d, dy)
+    kt = run.kt
+    new = lambda cols: _empty(Mq, cols, dy)                                      # noqa: E731
+    if live is not None:
+        Mq, kt = live.Mc, None
+        # rows of a live quad that belong to no sample's live prefix are never written by the attention kernel
+        new = lambda cols: torch.zeros(live.Mc + live.SLACK, cols, dtype=torch.float32, device=dy.device)[:live.Mc]   # noqa: E731
+        o_in, xq_in = live.gather(o), live.gather(xq)
+    else:
+        o_in, xq_in = o, xq
+    g = ops.dropout_bwd(dy, run.p, run.seed, site_o, live=live) if (fused and run.p > 0) else dy
+    ops.linear_wgrad([g], d, o_in, [G(m.out.weight)], [G(m.out.bias)], kt=kt)
+    do = _empty(Mq, d, dy) if live is None else live.empty(d)
     ops.linear_dgrad([g], d, Mq, [m.out.weight], do)
     if kvb is None:  # self-attention: fused [q|k|v]
-        dqkv = _empty(Mq, 3 * d, dy)
+        dqkv = new(3 * d)
         ops.attn_bwd(qb, qb[:, d:], qb[:, 2 * d:], 3 * d, 3 * d, 3 * d, mask_u8, o, do, lse, dqkv,
                      dqkv[:, d:], dqkv[:, 2 * d:], 3 * d, 3 * d, 3 * d, B, H, Lq, Lk, dk, run.p,
-                     run.seed, site_p)
+                     run.seed, site_p, live=live, kv_compact=live is not None)
         segs = [dqkv, dqkv[:, d:], dqkv[:, 2 * d:]]
-        ops.linear_wgrad(segs, 3 * d, xq,
+        ops.linear_wgrad(segs, 3 * d, xq_in,
                          [G(m.q_linear.weight), G(m.k_linear.weight), G(m.v_linear.weight)],
-                         [G(m.q_linear.bias), G(m.k_linear.bias), G(m.v_linear.bias)], kt=run.kt)
+                         [G(m.q_linear.bias), G(m.k_linear.bias), G(m.v_linear.bias)], kt=kt)
         ops.linear_dgrad(segs, 3 * d, Mq,
                          [m.q_linear.weight, m.k_linear.weight, m.v_linear.weight], dxq_out,
                          depi=depi_q)
     else:
-        dq = _empty(Mq, d, dy)
+        dq = new(d)
         dkv = _empty(Mk, 2 * d, dy)
         ops.attn_bwd(qb, kvb, kvb[:, d:], d, 2 * d, 2 * d, mask_u8, o, do, lse, dq, dkv, dkv[:, d:],
-                     d, 2 * d, 2 * d, B, H, Lq, Lk, dk, run.p, run.seed, site_p)
-        ops.linear_wgrad([dq], d, xq, [G(m.q_linear.weight)], [G(m.q_linear.bias)], kt=run.kt)   # query rows
+                     d, 2 * d, 2 * d, B, H, Lq, Lk, dk, run.p, run.seed, site_p, live=live)
+        ops.linear_wgrad([dq], d, xq_in, [G(m.q_linear.weight)], [G(m.q_linear.bias)], kt=kt)   # query rows
         ops.linear_wgrad([dkv, dkv[:, d:]], 2 * d, xkv,
                          [G(m.k_linear.weight), G(m.v_linear.weight)],
                          [G(m.k_linear.bias), G(m.v_linear.bias)])
@@ -182,16 +199,20 @@ def ffn_fwd(run: Run, ff, x, resid):
     return y, (x, pre, hdn, site_h, site_o, resid is not None)
 
 
-def ffn_bwd(run: Run, ff, saved, dy, G: GradSink, dx_out, depi):
+def ffn_bwd(run: Run, ff, saved, dy, G: GradSink, dx_out, depi, live=None):
     x, pre, hdn, site_h, site_o, fused = saved
     M, d = x.shape
     dff = pre.shape[1]
-    g = ops.dropout_bwd(dy, run.p, run.seed, site_o) if (fused and run.p > 0) else dy
-    ops.linear_wgrad([g], d, hdn, [G(ff.linear_2.weight)], [G(ff.linear_2.bias)], kt=run.kt)
-    dpre = _empty(M, dff, dy)
+    kt = run.kt
+    if live is not None:          # quad-compacted rows: gather what the forward saved
+        M, kt = live.Mc, None
+        x, pre, hdn = live.gather(x), live.gather(pre), live.gather(hdn)
+    g = ops.dropout_bwd(dy, run.p, run.seed, site_o, live=live) if (fused and run.p > 0) else dy
+    ops.linear_wgrad([g], d, hdn, [G(ff.linear_2.weight)], [G(ff.linear_2.bias)], kt=kt)
+    dpre = _empty(M, dff, dy) if live is None else live.empty(dff)
     ops.linear_dgrad([g], d, M, [ff.linear_2.weight], dpre, depi=ops.DEPI_GELU_BWD, pre=pre,
-                     p=run.p, seed=run.seed, site=site_h)
-    ops.linear_wgrad([dpre], dff, x, [G(ff.linear_1.weight)], [G(ff.linear_1.bias)], kt=run.kt)
+                     p=run.p, seed=run.seed, site=site_h, live=live)
+    ops.linear_wgrad([dpre], dff, x, [G(ff.linear_1.weight)], [G(ff.linear_1.bias)], kt=kt)
     ops.linear_dgrad([dpre], dff, M, [ff.linear_1.weight], dx_out, depi=depi)
 
 
@@ -228,19 +249,20 @@ def dec_layer_fwd(run: Run, layer, x, e, B, T, Lk, src_mask_u8, trg_mask_u8, wan
     return xc, (x, m1, r1, sv1, xa, m2, r2, sv2, xb, m3, r3, svf), p1, p2
 
 
-def dec_layer_bwd(run: Run, layer, saved, g, de, first_de, G: GradSink):
+def dec_layer_bwd(run: Run, layer, saved, g, de, first_de, G: GradSink, live=None):
+    """live (ops.LiveRows): g and every row-wise gradient of this layer are quad-compacted [live.Mc, d]."""
     x, m1, r1, sv1, xa, m2, r2, sv2, xb, m3, r3, svf = saved
-    t = torch.empty_like(g)
-    ffn_bwd(run, layer.ff, svf, g, G, t, ops.DEPI_STORE)
+    t = torch.empty_like(g) if live is None else live.empty(g.shape[1])
+    ffn_bwd(run, layer.ff, svf, g, G, t, ops.DEPI_STORE, live=live)
     ops.norm_bwd(t, xb, layer.norm_3.alpha, m3, r3, G(layer.norm_3.alpha), G(layer.norm_3.bias),
-                 dres=g, out=g, eps=layer.norm_3.eps)
+                 dres=g, out=g, eps=layer.norm_3.eps, live=live)
     mha_bwd(run, layer.attn_2, sv2, g, G, t, ops.DEPI_STORE, de,
-            ops.DEPI_STORE if first_de else ops.DEPI_ACCUM)
+            ops.DEPI_STORE if first_de else ops.DEPI_ACCUM, live=live)
     ops.norm_bwd(t, xa, layer.norm_2.alpha, m2, r2, G(layer.norm_2.alpha), G(layer.norm_2.bias),
-                 dres=g, out=g, eps=layer.norm_2.eps)
-    mha_bwd(run, layer.attn_1, sv1, g, G, t, ops.DEPI_STORE)
+                 dres=g, out=g, eps=layer.norm_2.eps, live=live)
+    mha_bwd(run, layer.attn_1, sv1, g, G, t, ops.DEPI_STORE, live=live)
     ops.norm_bwd(t, x, layer.norm_1.alpha, m1, r1, G(layer.norm_1.alpha), G(layer.norm_1.bias),
-                 dres=g, out=g, eps=layer.norm_1.eps)
+                 dres=g, out=g, eps=layer.norm_1.eps, live=live)
     return g
 
 
@@ -339,22 +361,42 @@ def decoder_trunk_fwd(dec, run: Run, trg, z, src_mask_u8, trg_mask_u8, dconds, w
 def decoder_trunk_bwd(dec, run: Run, saved, dy, G: GradSink, need_dz=True):
     trg, z2, dconds, site_pe, lsv, x_last, mean, rstd, B, T, Le, Lk, c2d, c2l, trg_mask_u8 = saved
     d, nc = dec.d_model, dec.nconds
-    g = dy.reshape(B * T, d).clone()
-    # A decoder row whose incoming gradient is zero (padded target positions under the ignore_index loss)
-    # keeps a zero gradient through every layer below -- norm, linear, GELU and dropout backward map a zero row
-    # to a zero row, attention gives zero dQ rows for zero dO rows -- PROVIDED no live query attends to it (a dead
-    # row that is a visible key receives dK / dV).  ops.LiveRows derives the live rows from the gradient and checks
-    # that proviso on the device against the trg_mask this call used (csrc/liverows.hip); its tile list names
-    # every tile when the check fails, so the weight-gradient GEMMs below stay exact for any mask / loss.
-    run.kt = ops.LiveRows(g, B, T, trg_mask_u8, lists=False).kt if (B * T) % 32 == 0 else None
-    ops.norm_bwd(g, x_last, dec.norm.alpha, mean, rstd, G(dec.norm.alpha), G(dec.norm.bias), out=g,
-                 eps=dec.norm.eps)
-    de = _empty(B * Lk, d, g)
-    first = True
-    for layer, sv in zip(reversed(dec.layers), reversed(lsv)):
-        g = dec_layer_bwd(run, layer, sv, g, de, first, G)
-        first = False
-    run.kt = None
+    # A decoder row whose incoming gradient is zero (padded target positions under the ignore_index loss: 56 % of
+    # the rows at MOSES-like lengths) keeps a zero gradient through every layer below -- norm, linear, GELU and
+    # dropout backward map a zero row to a zero row, attention gives zero dQ rows for zero dO rows -- PROVIDED no live
+    # query attends to it (a dead row that is a visible key receives dK / dV).  ops.LiveRows derives the live rows
+    # from the gradient and checks that proviso on the device against the trg_mask this call used
+    # (csrc/liverows.hip).  When it holds (and pays), the whole decoder backward runs on the QUAD-COMPACTED live
+    # rows: every GEMM, norm and dropout backward sees ~half the rows; otherwise the dense path runs, with the
+    # weight-gradient GEMMs reducing over the live token tiles (the list names every tile when the check fails).
+    g = dy.reshape(B * T, d)
+    live = None
+    lr = ops.LiveRows(g, B, T, trg_mask_u8) if (COMPACT_BWD or (B * T) % 32 == 0) else None
+    if COMPACT_BWD and lr is not None and len(dec.layers) > 0 and not torch.cuda.is_current_stream_capturing():
+        h = lr.host()                                   # one 32-byte read-back per step
+        if h["violations"] == 0 and h["nonprefix"] == 0 and 0 < h["padded"] <= COMPACT_MAX_FRACTION * B * T:
+            live = lr
+    if live is not None:
+        gc = live.gather(g)
+        ops.norm_bwd(gc, x_last, dec.norm.alpha, mean, rstd, G(dec.norm.alpha), G(dec.norm.bias), out=gc,
+                     eps=dec.norm.eps, live=live)
+        de = _empty(B * Lk, d, g)
+        first = True
+        for layer, sv in zip(reversed(dec.layers), reversed(lsv)):
+            gc = dec_layer_bwd(run, layer, sv, gc, de, first, G, live=live)
+            first = False
+        g = live.scatter(gc)                            # back to [B*T, d]: zero rows where nothing was live
+    else:
+        g = g.clone()
+        run.kt = lr.kt if (lr is not None and (B * T) % 32 == 0) else None
+        ops.norm_bwd(g, x_last, dec.norm.alpha, mean, rstd, G(dec.norm.alpha), G(dec.norm.bias), out=g,
+                     eps=dec.norm.eps)
+        de = _empty(B * Lk, d, g)
+        first = True
+        for layer, sv in zip(reversed(dec.layers), reversed(lsv)):
+            g = dec_layer_bwd(run, layer, sv, g, de, first, G)
+            first = False
+        run.kt = None
     if len(dec.layers) == 0:
         de.zero_()
     # embedding side

@@ -112,13 +112,17 @@ def norm_fwd(x2d, alpha, bias, eps=1e-6, out=None):
     return y, mean, rstd
 
 
-def norm_bwd(dy, x2d, alpha, mean, rstd, dalpha, dbias, dres=None, out=None, eps=1e-6):
-    rows, d = x2d.shape
-    dx = torch.empty_like(x2d) if out is None else out
+def norm_bwd(dy, x2d, alpha, mean, rstd, dalpha, dbias, dres=None, out=None, eps=1e-6, live=None):
+    """live (LiveRows): dy / dres / out are quad-compacted rows [live.Mc, d]; x2d, mean, rstd stay in the forward's
+    row space."""
+    src_rows, d = x2d.shape
+    rows = src_rows if live is None else live.Mc
+    dx = (torch.empty_like(x2d) if live is None else live.empty(d)) if out is None else out
     _wait_pending(out)
     ws = workspace(_L().gct_rowred_ws_bytes(rows, 2 * d), x2d.device)
     check(_L().gct_norm_bwd(_p(dy), _p(x2d), _p(alpha), _p(mean), _p(rstd), _p(dres), _p(dx),
-                            _p(dalpha), _p(dbias), _p(ws), rows, d, eps, _st()), "gct_norm_bwd")
+                            _p(dalpha), _p(dbias), _p(ws), rows, d, eps,
+                            None if live is None else _p(live.quad_list), src_rows, _st()), "gct_norm_bwd")
     return dx
 
 
@@ -278,7 +282,7 @@ def linear_fwd(x2d, ws_: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Ten
 
 
 def linear_dgrad(dys: Sequence[torch.Tensor], lddy: int, M: int, ws_: Sequence[torch.Tensor], dx,
-                 depi=DEPI_STORE, pre=None, p=0.0, seed=0, site=0):
+                 depi=DEPI_STORE, pre=None, p=0.0, seed=0, site=0, live=None):
     nper, K = ws_[0].shape
     d = _seg3(dys)
     w = _seg3(ws_)
@@ -289,7 +293,8 @@ def linear_dgrad(dys: Sequence[torch.Tensor], lddy: int, M: int, ws_: Sequence[t
         wsb = workspace(need, dx.device) if need > 256 else None
         check(_L().gct_linear_dgrad_p(d[0], d[1], d[2], lddy, M, len(ws_), nper, w[0], w[1], w[2],
                                       ws_[0].stride(0), wp, pstride, K, _p(dx), dx.stride(0), depi,
-                                      _p(pre), p, seed, site, _p(wsb), _st()), "gct_linear_dgrad_p")
+                                      _p(pre), p, seed, site, _p(wsb),
+                                      None if live is None else _p(live.quad_list), _st()), "gct_linear_dgrad_p")
 
 
 def nonzero_row_tiles(x2d: torch.Tensor):
@@ -308,22 +313,27 @@ def nonzero_row_tiles(x2d: torch.Tensor):
 
 
 class LiveRows:
-    """Device-side description of the rows of a decoder gradient that are not identically zero, plus the check
-    that makes shortcuts on them exact (csrc/liverows.hip).  `kt` feeds linear_wgrad(kt=...): it lists every tile
-    when the check failed, so it needs no host decision.  `host()` reads the five counters back (one sync)."""
+    """Device-side description of the rows of a decoder gradient that are not identically zero, the check that makes
+    shortcuts on them exact, and the compaction map of the decoder backward (csrc/liverows.hip).
+      kt          feeds linear_wgrad(kt=...): lists every tile when the check failed -- no host decision needed;
+      host()      reads the counters back (ONE device->host sync);
+      quad_list / cstart / n_b / Mc  (after host()): rows are compacted in aligned quads, compact row 4i+e <->
+                  original row 4*quad_list[i]+e, Mc compact rows (multiple of 128)."""
+    SLACK = 256        # rows behind Mc in every compact buffer: attention stages whole L-row windows of a sample
 
     def __init__(self, g2d, B, T, mask_u8, lists=True):
         _chk(g2d, "g2d")
         dev = g2d.device
         M = B * T
         assert g2d.shape[0] == M
-        nt = (M + 31) // 32
+        nt, nq = (M + 31) // 32, (M + 3) // 4
         i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)            # noqa: E731
-        self.B, self.T, self.M = B, T, M
+        self.B, self.T, self.M, self.dev = B, T, M, dev
         self.live = torch.empty(max(M, 1), dtype=torch.uint8, device=dev)
         self.n_b, self.info = i32(B), i32(8)
-        self.row_off = i32(B + 1) if lists else None
-        self.row_list = i32(M + 128) if lists else None
+        self.cstart = i32(B) if lists else None
+        self.quad_list = i32(nq + 32) if lists else None
+        qrank = i32(nq) if lists else None
         self.tile_list, self.tile_count = i32(nt), i32(1)
         flags = torch.empty(max(nt, 1), dtype=torch.uint8, device=dev)
         if mask_u8 is None:
@@ -332,16 +342,38 @@ class LiveRows:
             _chk(mask_u8, "live_rows.mask", torch.uint8)
             sb, sq = _mask_strides(mask_u8, B, T, T)
         check(_L().gct_live_rows(_p(g2d), g2d.stride(0), B, T, g2d.shape[1], _p(mask_u8), sb, sq, _p(self.live),
-                                 _p(self.n_b), _p(self.info), _p(self.row_off), _p(self.row_list),
+                                 _p(self.n_b), _p(self.info), _p(self.cstart), _p(self.quad_list), _p(qrank),
                                  _p(self.tile_list), _p(self.tile_count), _p(flags), _st()), "gct_live_rows")
         self.kt = (self.tile_list, self.tile_count)
         self._host = None
+        self.Mc = None
 
     def host(self):
         if self._host is None:
             v = self.info.tolist()
-            self._host = dict(n_live=v[0], violations=v[1], nonprefix=v[2], tiles=v[3], padded=v[4])
+            self._host = dict(n_live=v[0], violations=v[1], nonprefix=v[2], tiles=v[3], padded=v[4], quads=v[5])
+            self.Mc = v[4]
         return self._host
+
+    def empty(self, cols):
+        """A compact [Mc, cols] activation (with SLACK rows of allocation behind it)."""
+        return torch.empty(self.Mc + self.SLACK, cols, dtype=torch.float32, device=self.dev)[:self.Mc]
+
+    def gather(self, src2d, out=None):
+        """src2d [M, cols] (row stride >= cols) -> compact [Mc, cols]; padding rows are zero."""
+        cols = src2d.shape[1]
+        dst = self.empty(cols) if out is None else out
+        check(_L().gct_gather_quads(_p(src2d), src2d.stride(0), src2d.shape[0], _p(self.quad_list), self.Mc, cols,
+                                    _p(dst), dst.stride(0), _st()), "gct_gather_quads")
+        return dst
+
+    def scatter(self, src2d, out=None):
+        """compact [Mc, cols] -> [M, cols], zero rows where nothing is live."""
+        cols = src2d.shape[1]
+        dst = torch.zeros(self.M, cols, dtype=torch.float32, device=self.dev) if out is None else out
+        check(_L().gct_scatter_quads(_p(src2d), src2d.stride(0), _p(self.quad_list), self.Mc, cols, _p(dst),
+                                     dst.stride(0), self.M, _st()), "gct_scatter_quads")
+        return dst
 
 
 def linear_wgrad(dys: Sequence[torch.Tensor], lddy: int, x2d, dws: Sequence[torch.Tensor],
@@ -378,12 +410,14 @@ def linear_wgrad(dys: Sequence[torch.Tensor], lddy: int, x2d, dws: Sequence[torc
         _PENDING[t.untyped_storage().data_ptr()] = done
 
 
-def dropout_bwd(dout2d, p, seed, site, out=None):
+def dropout_bwd(dout2d, p, seed, site, out=None, live=None):
     rows, cols = dout2d.shape
+    if live is not None:
+        rows = live.Mc
     dy = torch.empty_like(dout2d) if out is None else out
     _wait_pending(out)
-    check(_L().gct_dropout_bwd(_p(dout2d), _p(dy), rows, cols, p, seed, site, _st()),
-          "gct_dropout_bwd")
+    check(_L().gct_dropout_bwd(_p(dout2d), _p(dy), rows, cols, p, seed, site,
+                               None if live is None else _p(live.quad_list), _st()), "gct_dropout_bwd")
     return dy
 
 
@@ -435,12 +469,14 @@ def attn_fwd(q, k, v, ld_q, ld_k, ld_v, mask, B, H, Lq, Lk, dk, p, seed, site, o
 
 
 def attn_bwd(q, k, v, ld_q, ld_k, ld_v, mask, o, dout, lse, dq, dk_, dv, ld_dq, ld_dk, ld_dv,
-             B, H, Lq, Lk, dk, p, seed, site):
+             B, H, Lq, Lk, dk, p, seed, site, live=None, kv_compact=False):
+    """live (LiveRows): dout / dq are quad-compacted; kv_compact: so are dk / dv (self-attention)."""
     mp, sb, sq = _mb(mask, B, Lq, Lk)
     check(_L().gct_attn_bwd(_p(q), ld_q, _p(k), ld_k, _p(v), ld_v, mp, sb, sq, _p(o),
                             _p(dout), o.stride(0), _p(lse), _p(dq), ld_dq, _p(dk_), ld_dk,
                             _p(dv), ld_dv, B, H, Lq, Lk, dk, 1.0 / math.sqrt(dk), p, seed, site,
-                            _st()), "gct_attn_bwd")
+                            None if live is None else _p(live.cstart), None if live is None else _p(live.n_b),
+                            int(bool(kv_compact)), _st()), "gct_attn_bwd")
 
 
 def _mask_strides(mask_u8, B, Lq, Lk):

@@ -37,7 +37,7 @@ extern "C" {
 #define GCT_ERR_ARG (-1)  /* bad shape / alignment / null pointer            */
 #define GCT_ERR_HIP (-2)  /* a HIP runtime call failed (launch error)        */
 
-#define GCT_ABI_VERSION 3
+#define GCT_ABI_VERSION 4
 
 int gct_version(void);
 const char* gct_last_error(void);
@@ -51,10 +51,13 @@ int64_t gct_rowred_ws_bytes(int64_t rows, int64_t cols);
  * Saves mean[rows] and rstd[rows] = 1/(std+eps) for the backward. d % 4 == 0, d <= 2048. */
 int gct_norm_fwd(const float* x, const float* alpha, const float* bias, float* y,
                  float* mean, float* rstd, int64_t rows, int d, float eps, void* stream);
-/* dx = dNorm/dx (dy) [+ dres]; dalpha, dbias overwritten. ws >= gct_rowred_ws_bytes(rows, 2*d). */
+/* dx = dNorm/dx (dy) [+ dres]; dalpha, dbias overwritten. ws >= gct_rowred_ws_bytes(rows, 2*d).
+ * quad_map (nullable): dy / dres / dx are QUAD-COMPACTED rows (see gct_live_rows) while x, mean, rstd stay in the
+ * forward's row space of src_rows rows: compact row 4i+e reads x row 4*quad_map[i]+e. */
 int gct_norm_bwd(const float* dy, const float* x, const float* alpha, const float* mean,
                  const float* rstd, const float* dres, float* dx, float* dalpha, float* dbias,
-                 float* ws, int64_t rows, int d, float eps, void* stream);
+                 float* ws, int64_t rows, int d, float eps, const int32_t* quad_map, int64_t src_rows,
+                 void* stream);
 
 /* --------------------------------------------------- K1: embedding + PE (+cond) */
 /* Model/modules.py:108-110 (lookup), :134-144 (x*sqrt(d)+pe, dropout),
@@ -163,7 +166,9 @@ int gct_linear_dgrad_p(const float* dy0, const float* dy1, const float* dy2, int
                        const float* w0, const float* w1, const float* w2, int64_t ldw,
                        const uint16_t* wp0, int64_t plane_stride, int K,
                        float* dx, int64_t lddx, int depi, const float* pre, float p, uint64_t seed,
-                       uint32_t site, float* ws, void* stream);
+                       uint32_t site, float* ws, const int32_t* quad_map, void* stream);
+/* quad_map (nullable): the M rows are quad-compacted (gct_live_rows); GCT_DEPI_GELU_BWD then regenerates the dropout
+ * mask of compact quad q from original quad quad_map[q] (pre is compact like dy / dx). */
 /* ws of gct_linear_dgrad_p (nullable): >= gct_linear_dgrad_ws_bytes(M, nseg*nper, K).  With a workspace the
  * bf16x6 forward / dgrad launches balance a partial last round of tiles (K-split tail launch + fix-up kernel);
  * gct_linear_fwd_ws_bytes covers the forward (skinny split-K or tail slabs, whichever the launch would use). */
@@ -178,30 +183,38 @@ int64_t gct_linear_dgrad_ws_bytes(int64_t M, int Ntot, int K);
 int gct_nonzero_row_tiles(const float* x, int64_t ld, int64_t rows, int cols, int32_t* list,
                           int32_t* count, uint8_t* flags_ws, void* stream);
 /* The property above holds only if no live query row attends to a dead (zero-gradient) row: a dead row that is a
- * VISIBLE KEY of a live query receives dK / dV.  gct_live_rows derives the live rows of g[B*T][cols] and CHECKS the
- * property on the device against the self-attention mask actually used (mask element (b,i,j) at
- * mask[b*mask_sb + i*mask_sq + j]; NULL = everything visible; mask_sq == 0 = key-padding mask):
+ * VISIBLE KEY of a live query receives dK / dV (and a live row that sees NO key attends uniformly to all of them).
+ * gct_live_rows derives the live rows of g[B*T][cols] and CHECKS the property on the device against the
+ * self-attention mask actually used (mask element (b,i,j) at mask[b*mask_sb + i*mask_sq + j]; NULL = everything
+ * visible; mask_sq == 0 = key-padding mask):
  *   live [B*T] u8; n_b [B] live rows per sample;
- *   info [8] i32: [0] live rows, [1] samples with a dead key visible to a live query (violations),
- *                 [2] samples whose live rows are not the prefix 0..n_b-1, [3] listed token tiles,
- *                 [4] length of row_list (live rows rounded up to a multiple of 128);
- *   row_off  [B+1] (nullable) exclusive prefix sum of n_b;
- *   row_list [B*T+128] (nullable) ascending live row ids, padded with -1;
+ *   info [8] i32: [0] live rows, [1] samples that violate the property, [2] samples whose live rows are not the
+ *                 prefix 0..n_b-1, [3] listed token tiles, [4] compact rows (multiple of 128), [5] live quads;
  *   tile_list / tile_count / tile_flags_ws (nullable, together): the 32-row token tiles that hold a live row --
- *   EVERY tile when info[1] != 0, so gct_linear_wgrad_kt stays exact without a host round trip. */
+ *   EVERY tile when info[1] != 0, so gct_linear_wgrad_kt stays exact without a host round trip;
+ *   cstart [B] / quad_list [ceil(B*T/4)+32] / qrank_ws [ceil(B*T/4)] (nullable, together): the COMPACTION MAP of the
+ *   decoder backward.  Rows are compacted in aligned groups of 4 ("quads"), the granularity at which every dropout
+ *   site draws its Philox values: compact row 4i+e <-> original row 4*quad_list[i]+e (quad_list ascending, padded
+ *   with -1 to a multiple of 32 quads); sample b's row t sits at compact row cstart[b]+t.
+ * gct_gather_quads / gct_scatter_quads move rows between the two spaces (scatter: dst pre-zeroed by the caller). */
 int gct_live_rows(const float* g, int64_t ld, int B, int T, int cols, const uint8_t* mask, int64_t mask_sb,
-                  int64_t mask_sq, uint8_t* live, int32_t* n_b, int32_t* info, int32_t* row_off,
-                  int32_t* row_list, int32_t* tile_list, int32_t* tile_count, uint8_t* tile_flags_ws,
-                  void* stream);
+                  int64_t mask_sq, uint8_t* live, int32_t* n_b, int32_t* info, int32_t* cstart,
+                  int32_t* quad_list, int32_t* qrank_ws, int32_t* tile_list, int32_t* tile_count,
+                  uint8_t* tile_flags_ws, void* stream);
+int gct_gather_quads(const float* src, int64_t ld, int64_t M, const int32_t* quad_list, int64_t nrows, int cols,
+                     float* dst, int64_t ldd, void* stream);
+int gct_scatter_quads(const float* src, int64_t ld, const int32_t* quad_list, int64_t nrows, int cols, float* dst,
+                      int64_t ldd, int64_t M, void* stream);
 int gct_linear_wgrad_kt(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
                         int64_t M, int nseg, int nper, const float* x, int64_t ldx, int K,
                         float* dw0, float* dw1, float* dw2, int64_t lddw,
                         float* db0, float* db1, float* db2, float* ws,
                         const int32_t* kt_list, const int32_t* kt_count, void* stream);
 
-/* elementwise dropout backward for the GCT_EPI_DROP_RESID sites: dy = dropmask*dout/(1-p) */
+/* elementwise dropout backward for the GCT_EPI_DROP_RESID sites: dy = dropmask*dout/(1-p); quad_map (nullable):
+ * the rows are quad-compacted, the mask of compact quad q is that of original quad quad_map[q] */
 int gct_dropout_bwd(const float* dout, float* dy, int64_t rows, int cols, float p, uint64_t seed,
-                    uint32_t site, void* stream);
+                    uint32_t site, const int32_t* quad_map, void* stream);
 
 /* ------------------------------------------------------------- K4: attention */
 /* Model/sublayers.py:29-41 attention() + head split/merge :64-69.
@@ -222,13 +235,16 @@ int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const
                  int64_t ldv, const uint32_t* mbits, int64_t mb_sb, int64_t mb_sq,
                  float* o, int64_t ldo, float* lse, float* probs, int B, int H, int Lq, int Lk,
                  int dk, float scale, float p, uint64_t seed, uint32_t site, void* stream);
-/* dq/dk/dv written (overwrite) with the same layout as q/k/v. */
+/* dq/dk/dv written (overwrite) with the same layout as q/k/v.
+ * cstart / nlive (nullable, together): dout and dq are quad-compacted (gct_live_rows): the rows of sample b start at
+ * cstart[b] and only its first nlive[b] query rows exist; kv_compact != 0 (self-attention, Lq == Lk): dk / dv live
+ * in those compact rows too.  q, k, v, o, lse stay in the forward's layout. */
 int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
                  int64_t ldv, const uint32_t* mbits, int64_t mb_sb, int64_t mb_sq,
                  const float* o, const float* dout, int64_t ldo, const float* lse,
                  float* dq, int64_t lddq, float* dk_, int64_t lddk, float* dv, int64_t lddv,
                  int B, int H, int Lq, int Lk, int dk, float scale, float p, uint64_t seed,
-                 uint32_t site, void* stream);
+                 uint32_t site, const int32_t* cstart, const int32_t* nlive, int kv_compact, void* stream);
 
 /* ------------------------------------------------- K6: reparameterisation + KL */
 /* Model/sublayers.py:14-20 / Model/cvaetf.py:63-69: z = eps*exp(0.5*log_var)+mu.

@@ -498,6 +498,38 @@ def test_zero_gradient_rows_with_arbitrary_masks_vs_oracle(case):
         assert_close(p.grad, e, 1e-5 * float(e.abs().max()) + floor, 1e-3, f"{case}: grad {name}")
 
 
+@pytest.mark.parametrize("mtype,kw,B,S,p", [("pscavaetf", {}, 9, 70, 0.0), ("pvaetf", {}, 16, 77, 0.2),
+                                            ("vaetf", dict(N=2, d_model=512, dff=2048, h=8, latent_dim=128), 48, 80, 0.1)])
+def test_compacted_decoder_backward_matches_dense(mtype, kw, B, S, p, monkeypatch):
+    """The decoder backward on quad-compacted live rows (engine.decoder_trunk_bwd, csrc/liverows.hip) against the
+    dense path on the same inputs, seeds and dropout masks: every parameter gradient.  The dropout cases prove that
+    the mask of a compact quad is regenerated from its ORIGINAL quad (GEMM epilogue, dropout backward, attention)."""
+    from gct_plus_amd import engine
+    ds = synthetic.make_dataset(B, S, mtype, seed=31)
+    nc = synthetic.n_conds(mtype)
+    eps = torch.randn(B, S + nc, kw.get("latent_dim", TINY["latent_dim"]), generator=torch.Generator().manual_seed(2))
+    grads, took = {}, {}
+    for mode in (True, False):
+        monkeypatch.setattr(engine, "COMPACT_BWD", mode)
+        seen = []
+        real = engine.ops.LiveRows.gather
+        monkeypatch.setattr(engine.ops.LiveRows, "gather", lambda self, *a, **k: (seen.append(1), real(self, *a, **k))[1])
+        torch.manual_seed(77)
+        engine._SEED["base"] = None                      # same dropout seeds in both runs
+        model = build(mtype, dropout=p, seed=5, **kw).train()
+        set_eps(model, eps)
+        loss = run_fwd_loss(model, mtype, ds, 0.04)[5]
+        loss.backward()
+        torch.cuda.synchronize()
+        grads[mode] = {n: q.grad.detach().clone() for n, q in model.named_parameters() if q.grad is not None}
+        took[mode] = len(seen)
+        monkeypatch.setattr(engine.ops.LiveRows, "gather", real)
+    assert took[True] > 0 and took[False] == 0           # the compact path really ran (and only when enabled)
+    floor = grad_floor(list(grads[False].values()))
+    for n, e in grads[False].items():
+        assert_close(grads[True][n], e, 2e-6 * float(e.abs().max()) + floor, 2e-5, f"compact vs dense: {n}")
+
+
 def test_greedy_decode_token_ids_bit_exact(golden_dir):
     """G5: argmax-decoded ids from model.decode equal the reference's."""
     from gct_plus_amd.Model import get_trg_mask
