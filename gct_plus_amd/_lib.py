@@ -61,8 +61,10 @@ SIGNATURES = {
     "gct_kld_bwd": (I32, [P, P, P, P, P, I64, P]),
     "gct_ce_fwd": (I32, [P, P, P, P, I64, I32, I64, P]),
     "gct_ce_bwd": (I32, [P, P, P, P, I64, I32, I64, P]),
-    "gct_attn_decode": (I32, [P, I64, P, P, I64, I64, P, I64, P, I64, I32, I32, I32, I32, F32, P]),
-    "gct_select_token": (I32, [P, I32, P, I64, I32, P, I64, P, P, I32, I32, I64, I64, U64, P]),
+    "gct_attn_decode": (I32, [P, I64, P, P, I64, I64, P, I64, P, I64, I32, I32, I32, I32, F32, P, I32, P, P, I64, P]),
+    "gct_decode_embed": (I32, [P, I64, P, I32, P, I32, P, P, I32, I32, F32, P]),
+    "gct_decode_advance": (I32, [P, P]),
+    "gct_select_token": (I32, [P, I32, P, I64, I32, P, I64, P, P, I32, I32, I64, I64, U64, P, I32, P, P]),
     "gct_smiles_tokenize": (I32, [C.c_char_p, I32, P, P, I32]),
     "gct_smiles_encode_batch": (I32, [P, I32, I32, P, I32, I64, I64, I64, I64, P, I64, P]),
     "gct_adam_step": (I32, [P, P, P, P, I64, F32, F32, F32, F32, I64, F32, P]),

@@ -9,36 +9,64 @@
 
 namespace {
 
-// one wave per (b, h); 16 lanes per key for the scores (4 keys per pass), lanes over d for P.V
+// one wave per (b, h); 16 lanes per key for the scores (4 keys per pass), lanes over d for P.V.
+// pos (nullable): DEVICE-side step counter -- the cache holds Lc = cache_off + *pos keys, and the step's own key /
+// value (knew / vnew, row b of a [n][ldn] step buffer) are the last key: they are appended to the caches here
+// (row Lc) and scored from registers, so ONE captured graph serves every step of the decode loop.
 template <int DK>
 __global__ __launch_bounds__(256) void attn_decode_kernel(
-    const float* __restrict__ q, int64_t ldq, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ q, int64_t ldq, float* __restrict__ k, float* __restrict__ v,
     int64_t kv_row, int64_t kv_batch, const uint8_t* __restrict__ valid, int64_t valid_sb,
-    float* __restrict__ o, int64_t ldo, int n, int H, int Lc, float scale) {
+    float* __restrict__ o, int64_t ldo, int n, int H, int Lc_host, float scale,
+    const int32_t* __restrict__ pos, int cache_off, const float* __restrict__ knew,
+    const float* __restrict__ vnew, int64_t ldn) {
   __shared__ float sc[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
   if (pair >= (int64_t)n * H) return;
   const int b = (int)(pair / H), h = (int)(pair - (int64_t)b * H);
+  const int Lold = pos ? cache_off + *pos : Lc_host;          // keys already in the cache
+  const int Lc = pos ? Lold + 1 : Lold;
   const float* qp = q + (int64_t)b * ldq + h * DK;
-  const float* kp = k + (int64_t)b * kv_batch + h * DK;
-  const float* vp = v + (int64_t)b * kv_batch + h * DK;
+  float* kp = k + (int64_t)b * kv_batch + h * DK;
+  float* vp = v + (int64_t)b * kv_batch + h * DK;
   const uint8_t* vl = valid ? valid + (int64_t)b * valid_sb : nullptr;
   constexpr int LPK = DK / 4;        // lanes per key (float4 each)
   constexpr int KPP = 64 / LPK;      // keys per pass
   const int sub = lane % LPK, kslot = lane / LPK;
   const float4 qv = *reinterpret_cast<const float4*>(qp + sub * 4);
+  float vlast = 0.f;
+  if (pos) {
+    // this step's key: score it from the step buffer and append key / value to the caches
+    const float* kn = knew + (int64_t)b * ldn + h * DK;
+    const float* vn = vnew + (int64_t)b * ldn + h * DK;
+    float s = 0.f;
+    if (lane < LPK) {
+      const float4 kv4 = *reinterpret_cast<const float4*>(kn + lane * 4);
+      s = (qv.x * kv4.x + qv.y * kv4.y) + (qv.z * kv4.z + qv.w * kv4.w);   // sub == lane here
+      *reinterpret_cast<float4*>(kp + (int64_t)Lold * kv_row + lane * 4) = kv4;
+      *reinterpret_cast<float4*>(vp + (int64_t)Lold * kv_row + lane * 4) = *reinterpret_cast<const float4*>(vn + lane * 4);
+    }
+#pragma unroll
+    for (int off = LPK / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) {
+      s *= scale;
+      if (vl && vl[Lold] == 0) s = -1e9f;
+      sc[wave][Lold] = s;
+    }
+    if (lane < DK) vlast = vn[lane];
+  }
   float m = -INFINITY;
-  for (int j0 = 0; j0 < Lc; j0 += KPP) {
+  for (int j0 = 0; j0 < Lold; j0 += KPP) {
     const int j = j0 + kslot;
     float s = 0.f;
-    if (j < Lc) {
+    if (j < Lold) {
       const float4 kv4 = *reinterpret_cast<const float4*>(kp + (int64_t)j * kv_row + sub * 4);
       s = (qv.x * kv4.x + qv.y * kv4.y) + (qv.z * kv4.z + qv.w * kv4.w);
     }
 #pragma unroll
     for (int off = LPK / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (j < Lc && sub == 0) {
+    if (j < Lold && sub == 0) {
       s *= scale;
       if (vl && vl[j] == 0) s = -1e9f;            // masked_fill(mask == 0, -1e9)
       sc[wave][j] = s;
@@ -60,20 +88,46 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
   __builtin_amdgcn_wave_barrier();
   if (lane < DK) {
     float acc = 0.f;
-    for (int j = 0; j < Lc; ++j) acc = fmaf(sc[wave][j] * inv, vp[(int64_t)j * kv_row + lane], acc);
+    for (int j = 0; j < Lold; ++j) acc = fmaf(sc[wave][j] * inv, vp[(int64_t)j * kv_row + lane], acc);
+    if (pos) acc = fmaf(sc[wave][Lold] * inv, vlast, acc);
     o[(int64_t)b * ldo + h * DK + lane] = acc;
   }
 }
 
+// x[b][:] = table[ys[b][*pos]] * scale + pe[pe_off + *pos][:]   (Embeddings + PositionalEncoding of ONE position)
+__global__ __launch_bounds__(256) void decode_embed_kernel(const int64_t* __restrict__ ys, int64_t ld_ys,
+                                                           const int32_t* __restrict__ pos, int pe_off,
+                                                           const float* __restrict__ table, int vocab,
+                                                           const float* __restrict__ pe, float* __restrict__ out,
+                                                           int n, int d, float scale) {
+  const int p = *pos;
+  const int64_t total = (int64_t)n * (d / 4);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)(i / (d / 4)), c = (int)(i - (int64_t)b * (d / 4));
+    int64_t tok = ys[(int64_t)b * ld_ys + p];
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+    const float4 e = *reinterpret_cast<const float4*>(table + tok * d + c * 4);
+    const float4 q = *reinterpret_cast<const float4*>(pe + (int64_t)(pe_off + p) * d + c * 4);
+    *reinterpret_cast<float4*>(out + (int64_t)b * d + c * 4) =
+        make_float4(e.x * scale + q.x, e.y * scale + q.y, e.z * scale + q.z, e.w * scale + q.w);
+  }
+}
+
+__global__ void decode_advance_kernel(int32_t* pos) { *pos += 1; }
+
 __device__ __forceinline__ float u01_open(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
-// one wave per sample row
+// one wave per sample row.  pos_dev (nullable): device-side step counter -- the token is written at ys[.., *pos_dev + 1]
+// and valid[.., valid_off + *pos_dev + 1]; seed_dev (nullable) replaces the by-value seed of the multinomial draw
 __global__ __launch_bounds__(256) void select_token_kernel(const float* __restrict__ logits, int V,
-                                                           int64_t* ys, int64_t ld_ys, int pos,
+                                                           int64_t* ys, int64_t ld_ys, int pos_host,
                                                            uint8_t* valid, int64_t valid_sb,
                                                            uint8_t* done, float* probs_out, int n,
                                                            int mode, int64_t pad_id, int64_t eos_id,
-                                                           GctRng rng) {
+                                                           GctRng rng, const int32_t* __restrict__ pos_dev,
+                                                           int valid_off, const uint64_t* __restrict__ seed_dev) {
+  const int pos = pos_dev ? *pos_dev + 1 : pos_host;
+  if (seed_dev) rng = gct_rng_make(*seed_dev, 0xDEC0DEu);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= n) return;
@@ -131,18 +185,22 @@ __global__ __launch_bounds__(256) void select_token_kernel(const float* __restri
   }
   if (lane == 0) {
     ys[(int64_t)row * ld_ys + pos] = best;
-    if (valid) valid[(int64_t)row * valid_sb + pos] = (best != pad_id) ? 1 : 0;
+    if (valid) valid[(int64_t)row * valid_sb + valid_off + pos] = (best != pad_id) ? 1 : 0;
     if (done && best == eos_id) done[row] = 1;
   }
 }
 
 }  // namespace
 
-extern "C" int gct_attn_decode(const float* q, int64_t ldq, const float* k, const float* v,
+extern "C" int gct_attn_decode(const float* q, int64_t ldq, float* k, float* v,
                                int64_t kv_row, int64_t kv_batch, const uint8_t* valid,
                                int64_t valid_sb, float* o, int64_t ldo, int n, int H, int Lc, int dk,
-                               float scale, void* stream) {
-  GCT_CHECK_ARG(q && k && v && o && n >= 0 && H > 0 && Lc > 0 && Lc <= 256, "attn_decode: bad args");
+                               float scale, const int32_t* pos, int cache_off, const float* knew,
+                               const float* vnew, int64_t ldn, void* stream) {
+  GCT_CHECK_ARG(q && k && v && o && n >= 0 && H > 0 && Lc >= 0 && Lc <= 256, "attn_decode: bad args");
+  GCT_CHECK_ARG(pos || Lc > 0, "attn_decode: no keys");
+  GCT_CHECK_ARG(!pos || (knew && vnew && ldn % 4 == 0 && gct_aligned16(knew) && gct_aligned16(vnew) && cache_off >= 0),
+                "attn_decode: the device-position form needs this step's key / value rows");
   GCT_CHECK_ARG(dk == 16 || dk == 32 || dk == 64, "attn_decode: head dim %d unsupported", dk);
   GCT_CHECK_ARG(ldq % 4 == 0 && kv_row % 4 == 0 && kv_batch % 4 == 0 && gct_aligned16(q) &&
                     gct_aligned16(k) && gct_aligned16(v),
@@ -151,23 +209,43 @@ extern "C" int gct_attn_decode(const float* q, int64_t ldq, const float* k, cons
   const int64_t pairs = (int64_t)n * H;
   dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (dk == 64) hipLaunchKernelGGL(attn_decode_kernel<64>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale);
-  else if (dk == 32) hipLaunchKernelGGL(attn_decode_kernel<32>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale);
-  else hipLaunchKernelGGL(attn_decode_kernel<16>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale);
+  if (dk == 64) hipLaunchKernelGGL(attn_decode_kernel<64>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale, pos, cache_off, knew, vnew, ldn);
+  else if (dk == 32) hipLaunchKernelGGL(attn_decode_kernel<32>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale, pos, cache_off, knew, vnew, ldn);
+  else hipLaunchKernelGGL(attn_decode_kernel<16>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale, pos, cache_off, knew, vnew, ldn);
   GCT_LAUNCH_CHECK("attn_decode");
+  return GCT_OK;
+}
+
+extern "C" int gct_decode_embed(const int64_t* ys, int64_t ld_ys, const int32_t* pos, int pe_off, const float* table,
+                                int vocab, const float* pe, float* out, int n, int d, float scale, void* stream) {
+  GCT_CHECK_ARG(ys && pos && table && pe && out && n >= 0 && d > 0 && d % 4 == 0 && vocab > 0 && pe_off >= 0 &&
+                    gct_aligned16(table) && gct_aligned16(pe) && gct_aligned16(out),
+                "decode_embed: bad args");
+  if (n == 0) return GCT_OK;
+  const int64_t work = (int64_t)n * (d / 4);
+  hipLaunchKernelGGL(decode_embed_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ys,
+                     ld_ys, pos, pe_off, table, vocab, pe, out, n, d, scale);
+  GCT_LAUNCH_CHECK("decode_embed");
+  return GCT_OK;
+}
+
+extern "C" int gct_decode_advance(int32_t* pos, void* stream) {
+  GCT_CHECK_ARG(pos, "decode_advance: null pointer");
+  hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, pos);
+  GCT_LAUNCH_CHECK("decode_advance");
   return GCT_OK;
 }
 
 extern "C" int gct_select_token(const float* logits, int V, int64_t* ys, int64_t ld_ys, int pos,
                                 uint8_t* valid, int64_t valid_sb, uint8_t* done, float* probs_out,
                                 int n, int mode, int64_t pad_id, int64_t eos_id, uint64_t seed,
-                                void* stream) {
-  GCT_CHECK_ARG(logits && ys && V > 0 && n >= 0 && pos >= 0 && (mode == 0 || mode == 1),
+                                const int32_t* pos_dev, int valid_off, const uint64_t* seed_dev, void* stream) {
+  GCT_CHECK_ARG(logits && ys && V > 0 && n >= 0 && pos >= 0 && (mode == 0 || mode == 1) && valid_off >= 0,
                 "select_token: bad args");
   if (n == 0) return GCT_OK;
   hipLaunchKernelGGL(select_token_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0,
                      (hipStream_t)stream, logits, V, ys, ld_ys, pos, valid, valid_sb, done, probs_out,
-                     n, mode, pad_id, eos_id, gct_rng_make(seed, 0xDEC0DEu));
+                     n, mode, pad_id, eos_id, gct_rng_make(seed, 0xDEC0DEu), pos_dev, valid_off, seed_dev);
   GCT_LAUNCH_CHECK("select_token");
   return GCT_OK;
 }

@@ -4,14 +4,18 @@ The reference's Sampling.decode (Inference/sampling_tool.py:140-184) re-runs the
 on ys[:, :i+1] for every generated token -- fc_z(z), all six cross-attention K/V projections
 and every earlier position are recomputed 79 times, with one device->host sync per step.
 Because the decoder is causal, position j's hidden states depend only on tokens 0..j, so the
-same token ids come out of a single-token step that
-  * projects z and the cross-attention K/V of all layers ONCE (`start`),
-  * keeps per-layer self-attention q/k/v caches [n, T, d] -- the fused QKV GEMM writes its three
-    segments straight into the cache slots of position `pos` (segmented-output addressing),
-  * runs one query row per (sample, head) against the caches (gct_attn_decode),
-  * picks the next token, updates key-valid flags and the finished mask on the device
-    (gct_select_token) -- no host round trip inside a step, so a step is graph-capturable.
-Work per generated token drops from O(T) decoder passes to O(1).
+same token ids come out of
+  * `start`:   z and the cross-attention K/V of all layers projected ONCE;
+  * `prefill`: the prefix (<sos>, or <sos> scaffold <sep>; with use_cond2dec the n_c condition tokens in
+               front of it, which see each other and the first token -- Model/modules.py:19-26) through ONE ordinary
+               decoder forward, whose per-layer self-attention K/V fill the caches;
+  * `step`:    a single-token chain per generated token -- embedding row, 6 x [norm, fused QKV GEMM, single-query
+               attention that APPENDS the new key/value to the cache, out-proj+residual, cross-attention, FFN],
+               norm, vocabulary GEMM, fused softmax + argmax / multinomial that appends the token and updates the
+               key-valid and finished flags on the device.
+The step reads its position from a DEVICE-side counter (csrc/decode.hip), so one captured graph serves every step
+(`use_graphs=True`): no host round trip, no per-position capture.  Work per generated token drops from O(T) decoder
+passes to O(1).
 """
 from __future__ import annotations
 
@@ -20,33 +24,36 @@ from typing import Optional
 
 import torch
 
-from . import ops
+from . import engine, ops
+from ._lib import check
 
 
 class KVDecoder:
     def __init__(self, model, pad_id: int, sos_id: int, eos_id: int):
         dec = model.decoder
-        if dec.use_cond2dec and dec.nconds > 0:
-            raise NotImplementedError("KV-cached decode with use_cond2dec is not implemented; "
-                                      "use model.decode (no shipped script sets -use_cond2dec)")
         self.model, self.dec = model, dec
         self.pad_id, self.sos_id, self.eos_id = int(pad_id), int(sos_id), int(eos_id)
         self.d = dec.d_model
         self.H = dec.layers[0].attn_1.h
         self.dk = self.d // self.H
+        self.c2d = bool(dec.use_cond2dec and dec.nconds > 0)
+        self.off = dec.nconds if self.c2d else 0          # cache / positional index of token 0
         self.graphs = {}
+        self._shape = None
 
     # -------------------------------------------------------------------------------------
     @torch.no_grad()
     def start(self, z, src_mask, dconds=None, max_total_len=208):
-        """z [n, L_e, latent]; src_mask bool [n,1,L_e] (as the reference builds it)."""
+        """z [n, L_e, latent]; src_mask bool [n,1,L_e] (as the reference builds it); max_total_len = longest
+        token sequence (prefix + generated) this call may reach."""
         dec, d = self.dec, self.d
         dev = z.device
         n, Le, lat = z.shape
         if hasattr(self.model, "refresh_weight_planes"):
             self.model.refresh_weight_planes()         # the prefill GEMMs may take the bf16x6 path
         nc = dec.nconds
-        c2l = dec.use_cond2lat and nc > 0
+        c2l = (not self.c2d) and dec.use_cond2lat and nc > 0
+        self.z, self.src_mask_in, self.dconds = z, src_mask, dconds
         z2 = z.reshape(n * Le, lat).float().contiguous()
         ez = torch.empty(n * Le, d, device=dev)
         ops.linear_fwd(z2, [dec.fc_z.weight], [dec.fc_z.bias], [ez], d)
@@ -60,51 +67,92 @@ class KVDecoder:
             ops.copy_rows(cl, nc, 0, e, Lk, 0, n * nc, nc, d)
             ops.copy_rows(ez, Le, 0, e, Lk, nc, n * Le, Le, d)
             sv = torch.cat([torch.ones(n, nc, dtype=torch.uint8, device=dev), sv], dim=1)
-        self.src_valid = sv.contiguous()
-        self.n, self.Lk, self.T = n, Lk, int(max_total_len)
-        if self.T > 256 or Lk > 256:
+        T = int(max_total_len) + self.off              # cache rows: condition tokens (cond2dec) + tokens
+        if T > 256 or Lk > 256:
             raise ValueError("decode lengths above 256 are not supported by gct_attn_decode")
-        self.cross_kv = []
-        for layer in dec.layers:                                   # cross K/V: once per sequence
-            kv = torch.empty(n * Lk, 2 * d, device=dev)
-            a = layer.attn_2
+        shape = (n, Lk, T, str(dev))
+        if shape != self._shape:
+            # new geometry: new buffers, and the graphs captured against the old ones are dropped with them
+            # (they hold raw pointers: replaying them after a reallocation would write freed memory)
+            self.graphs = {}
+            self._shape = shape
+            self.n, self.Lk, self.T = n, Lk, T
+            self.cross_kv = [torch.empty(n * Lk, 2 * d, device=dev) for _ in dec.layers]
+            self.kc = [torch.empty(n, T, d, device=dev) for _ in dec.layers]
+            self.vc = [torch.empty(n, T, d, device=dev) for _ in dec.layers]
+            self.valid = torch.zeros(n, T, dtype=torch.uint8, device=dev)
+            self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
+            self.ys = torch.full((n, T), self.pad_id, dtype=torch.int64, device=dev)
+            self.src_valid = torch.empty(n, Lk, dtype=torch.uint8, device=dev)
+            self.pos = torch.zeros(1, dtype=torch.int32, device=dev)       # token index the next step consumes
+            self.seed = torch.zeros(1, dtype=torch.int64, device=dev)      # multinomial seed of this generate()
+            dff = dec.layers[0].ff.linear_1.weight.shape[0]
+            V = self.model.out.weight.shape[0]
+            wsb = max(ops._L().gct_linear_fwd_ws_bytes(n, dff, d), ops._L().gct_linear_fwd_ws_bytes(n, d, 3 * d),
+                      ops._L().gct_linear_fwd_ws_bytes(n, d, dff))
+            self.ws = torch.empty(wsb // 4 + 64, device=dev)           # split-K slabs of the skinny GEMMs
+            f = lambda *sh: torch.empty(*sh, device=dev)                # noqa: E731
+            self.buf = dict(x=f(n, d), x2=f(n, d), qkv=f(n, 3 * d), o=f(n, d), xa=f(n, d), q2=f(n, d), o2=f(n, d),
+                            xb=f(n, d), pre=f(n, dff), hdn=f(n, dff), xc=[f(n, d), f(n, d)], y=f(n, d),
+                            logits=f(n, V))
+        self.src_valid.copy_(sv)
+        for li, layer in enumerate(dec.layers):                    # cross K/V: once per sequence
+            kv, a = self.cross_kv[li], layer.attn_2
             ops.linear_fwd(e, [a.k_linear.weight, a.v_linear.weight], [a.k_linear.bias, a.v_linear.bias],
                            [kv, kv[:, d:]], 2 * d)
-            self.cross_kv.append(kv)
-        T = self.T
-        self.qc = [torch.empty(n, T, d, device=dev) for _ in dec.layers]
-        self.kc = [torch.empty(n, T, d, device=dev) for _ in dec.layers]
-        self.vc = [torch.empty(n, T, d, device=dev) for _ in dec.layers]
-        self.valid = torch.zeros(n, T, dtype=torch.uint8, device=dev)
-        self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
-        self.ys = torch.full((n, T), self.pad_id, dtype=torch.int64, device=dev)
-        # per-step scratch (fixed addresses => graph friendly)
-        dff = dec.layers[0].ff.linear_1.weight.shape[0]
-        V = self.model.out.weight.shape[0]
-        wsb = max(ops._L().gct_linear_fwd_ws_bytes(n, dff, d), ops._L().gct_linear_fwd_ws_bytes(n, d, 3 * d),
-                  ops._L().gct_linear_fwd_ws_bytes(n, d, dff))
-        self.ws = torch.empty(wsb // 4 + 64, device=dev)           # split-K slabs of the skinny GEMMs
-        f = lambda *s: torch.empty(*s, device=dev)
-        self.buf = dict(x2=f(n, d), o=f(n, d), xa=f(n, d), q2=f(n, d), o2=f(n, d), xb=f(n, d),
-                        pre=f(n, dff), hdn=f(n, dff), xc=[f(n, d), f(n, d)], y=f(n, d),
-                        logits=f(n, V), tok=torch.empty(n, 1, dtype=torch.int64, device=dev))
 
     # -------------------------------------------------------------------------------------
     @torch.no_grad()
-    def step(self, pos: int):
-        """Consume token ys[:, pos]; returns logits [n, V] for position pos+1."""
+    def prefill(self, ys0):
+        """The prefix ys0 [n, t0] (and, with use_cond2dec, the condition tokens in front of it) through one decoder
+        forward; fills the caches for positions < off + t0 and returns the logits of the last prefix position."""
+        from .Model.modules import get_trg_mask
+        dec, d, n = self.dec, self.d, self.n
+        t0 = ys0.shape[1]
+        ys0 = ys0.to(self.ys.device)
+        self.ys.fill_(self.pad_id)
+        self.ys[:, :t0] = ys0
+        self.valid.zero_()
+        self.valid[:, :self.off] = 1
+        self.valid[:, self.off:self.off + t0] = (ys0 != self.pad_id).to(torch.uint8)
+        self.done.zero_()
+        trg_mask = get_trg_mask(ys0, self.pad_id, self.c2d, self.dconds if dec.nconds > 0 else None)
+        run = engine.Run(0.0, False)
+        y, saved, _, _ = engine.decoder_trunk_fwd(dec, run, ys0.contiguous(), engine._f32c(self.z),
+                                                  ops.to_mask_u8(self.src_mask_in), ops.to_mask_u8(trg_mask),
+                                                  self.dconds)
+        Tp = self.off + t0
+        for li, sv in enumerate(saved[4]):                          # per layer: (x, m1, r1, sv1, ...); sv1[2] = q|k|v
+            qkv = sv[3][2].view(n, Tp, 3 * d)
+            self.kc[li][:, :Tp].copy_(qkv[:, :, d:2 * d])
+            self.vc[li][:, :Tp].copy_(qkv[:, :, 2 * d:])
+        out = self.model.out
+        ops.linear_fwd(y[:, -1].contiguous(), [out.weight], [out.bias], [self.buf["logits"]], out.weight.shape[0])
+        self.pos.fill_(t0 - 1)                                      # "token t0-1 has been consumed"
+        return self.buf["logits"]
+
+    # -------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self):
+        """Consume token ys[:, p] with p = *pos + 1 ... see _chain: ONE generated token, position on the device."""
         dec, d, n, T, B = self.dec, self.d, self.n, self.T, self.buf
-        B["tok"].copy_(self.ys[:, pos:pos + 1])
-        x = ops.embed_pe_fwd(B["tok"], dec.embed.embed.weight, None, dec.pe.pe[0, pos:], 0,
-                             math.sqrt(d), 0.0, 0, 0)
+        L = ops._L()
+        st = ops._st()
+        check(L.gct_decode_advance(self.pos.data_ptr(), st), "gct_decode_advance")   # pos = index of the token consumed now
+        check(L.gct_decode_embed(self.ys.data_ptr(), self.ys.stride(0), self.pos.data_ptr(), self.off,
+                                 dec.embed.embed.weight.data_ptr(), dec.embed.embed.weight.shape[0],
+                                 dec.pe.pe.data_ptr(), B["x"].data_ptr(), n, d, math.sqrt(d), st), "gct_decode_embed")
+        x = B["x"]
         for li, layer in enumerate(dec.layers):
             a1, a2, ff = layer.attn_1, layer.attn_2, layer.ff
             ops.norm_fwd(x, layer.norm_1.alpha, layer.norm_1.bias, layer.norm_1.eps, out=B["x2"])
-            qs, ks, vs = self.qc[li][:, pos], self.kc[li][:, pos], self.vc[li][:, pos]
+            qkv = B["qkv"]
             ops.linear_fwd(B["x2"], [a1.q_linear.weight, a1.k_linear.weight, a1.v_linear.weight],
-                           [a1.q_linear.bias, a1.k_linear.bias, a1.v_linear.bias], [qs, ks, vs], T * d, splitk_ws=self.ws)
-            ops.attn_decode(qs, T * d, self.kc[li], self.vc[li], d, T * d, self.valid, T, B["o"], n,
-                            self.H, pos + 1, self.dk)
+                           [a1.q_linear.bias, a1.k_linear.bias, a1.v_linear.bias],
+                           [qkv, qkv[:, d:], qkv[:, 2 * d:]], 3 * d, splitk_ws=self.ws)
+            ops.attn_decode(qkv, 3 * d, self.kc[li], self.vc[li], d, T * d, self.valid, T, B["o"], n,
+                            self.H, 0, self.dk, pos=self.pos, cache_off=self.off, knew=qkv[:, d:],
+                            vnew=qkv[:, 2 * d:], ldn=3 * d)
             ops.linear_fwd(B["o"], [a1.out.weight], [a1.out.bias], [B["xa"]], d,
                            epi=ops.EPI_DROP_RESID, resid=x, splitk_ws=self.ws)
             ops.norm_fwd(B["xa"], layer.norm_2.alpha, layer.norm_2.bias, layer.norm_2.eps, out=B["x2"])
@@ -126,6 +174,11 @@ class KVDecoder:
         ops.linear_fwd(B["y"], [out.weight], [out.bias], [B["logits"]], out.weight.shape[0])
         return B["logits"]
 
+    def _select(self, mode):
+        """softmax + choice of the next token from buf['logits']; written at ys[:, *pos + 1] (device position)."""
+        ops.select_token(self.buf["logits"], self.ys, 0, self.valid, self.done, mode, self.pad_id, self.eos_id,
+                         pos_dev=self.pos, valid_off=self.off, seed_dev=self.seed)
+
     # -------------------------------------------------------------------------------------
     @torch.no_grad()
     def generate(self, ys0, max_strlen=80, algo="greedy", seed=0, check_every=8, use_graphs=False):
@@ -133,20 +186,17 @@ class KVDecoder:
         (stops early once every sample has produced <eos>, like the reference's break)."""
         n, t0 = ys0.shape
         steps = max_strlen - 1
-        if t0 + steps > self.T:
-            raise ValueError(f"prefix {t0} + {steps} steps exceeds the cache length {self.T}")
+        if self.off + t0 + steps > self.T:
+            raise ValueError(f"prefix {t0} + {steps} steps exceeds the cache length {self.T - self.off}")
         mode = {"greedy": 0, "multinomial": 1}[algo]
-        self.ys[:, :t0] = ys0.to(self.ys.device)
-        self.valid[:, :t0] = (self.ys[:, :t0] != self.pad_id).to(torch.uint8)
-        self.done.zero_()
-        for pos in range(t0 - 1):                                  # prefix tokens fill the caches
-            self._run_step(pos, None, use_graphs)
+        self.seed.fill_(int(seed) & 0x7FFFFFFFFFFFFFFF)
+        self.prefill(ys0)
+        self._select(mode)                                         # token t0 from the prefill's last position
         last = t0 + steps
-        for i in range(steps):
-            pos = t0 - 1 + i
-            self._run_step(pos, (mode, seed), use_graphs)
+        for i in range(1, steps):
+            self._run_step(mode, use_graphs)                       # consumes token t0+i-1, writes token t0+i
             if check_every and (i + 1) % check_every == 0 and bool(self.done.all()):
-                last = pos + 2
+                last = t0 + i + 1
                 break
         ys = self.ys[:, :last]
         gen = ys[:, t0:]
@@ -157,29 +207,30 @@ class KVDecoder:
             ys = ys[:, :t0 + int(first.max().item()) + 1]
         return ys.clone()
 
-    def _run_step(self, pos, select, use_graphs):
+    def _run_step(self, mode, use_graphs):
         if not use_graphs:
-            logits = self.step(pos)
-            if select is not None:
-                ops.select_token(logits, self.ys, pos + 1, self.valid, self.done, select[0], self.pad_id,
-                                 self.eos_id, select[1])
+            self.step()
+            self._select(mode)
             return
-        key = (pos, select)
-        g = self.graphs.get(key)
+        g = self.graphs.get(mode)
         if g is None:
-            # warm-up run on a side stream (lazy LDS opt-ins, allocator), then capture
+            # Warm-up run on a side stream (lazy LDS opt-ins, allocator), then capture.  The warm-up really executes a
+            # step (it advances the device position and writes a token), so the state it touches is restored before
+            # the capture; a capture itself executes nothing.
+            keep = (self.pos.clone(), self.ys.clone(), self.valid.clone(), self.done.clone())
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                self.step(pos)
+                self.step()
+                self._select(mode)
             torch.cuda.current_stream().wait_stream(s)
+            # (the key / value row the warm-up appended is rewritten with the same values by the replay below)
+            self.pos.copy_(keep[0]); self.ys.copy_(keep[1]); self.valid.copy_(keep[2]); self.done.copy_(keep[3])
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                logits = self.step(pos)
-                if select is not None:
-                    ops.select_token(logits, self.ys, pos + 1, self.valid, self.done, select[0],
-                                     self.pad_id, self.eos_id, select[1])
-            self.graphs[key] = g
+                self.step()
+                self._select(mode)
+            self.graphs[mode] = g
         g.replay()
 
 

@@ -583,15 +583,17 @@ def add(a, b, out=None):
 
 
 # ----------------------------------------------------------------------------------- decode
-def attn_decode(q, ldq, k, v, kv_row, kv_batch, valid_u8, valid_sb, out, n, H, Lc, dk):
+def attn_decode(q, ldq, k, v, kv_row, kv_batch, valid_u8, valid_sb, out, n, H, Lc, dk, pos=None, cache_off=0,
+                knew=None, vnew=None, ldn=0):
     check(_L().gct_attn_decode(_p(q), ldq, _p(k), _p(v), kv_row, kv_batch, _p(valid_u8), valid_sb,
-                               _p(out), out.stride(0), n, H, Lc, dk, 1.0 / math.sqrt(dk), _st()),
-          "gct_attn_decode")
+                               _p(out), out.stride(0), n, H, Lc, dk, 1.0 / math.sqrt(dk), _p(pos), cache_off,
+                               _p(knew), _p(vnew), ldn, _st()), "gct_attn_decode")
 
 
-def select_token(logits2d, ys, pos, valid_u8, done_u8, mode, pad_id, eos_id, seed=0, probs_out=None):
+def select_token(logits2d, ys, pos, valid_u8, done_u8, mode, pad_id, eos_id, seed=0, probs_out=None, pos_dev=None,
+                 valid_off=0, seed_dev=None):
     n, V = logits2d.shape
     check(_L().gct_select_token(_p(logits2d), V, _p(ys), ys.stride(0), pos, _p(valid_u8),
                                 valid_u8.stride(0) if valid_u8 is not None else 0, _p(done_u8),
-                                _p(probs_out), n, mode, pad_id, eos_id, seed, _st()),
-          "gct_select_token")
+                                _p(probs_out), n, mode, pad_id, eos_id, seed, _p(pos_dev), valid_off, _p(seed_dev),
+                                _st()), "gct_select_token")

@@ -286,16 +286,27 @@ int gct_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
  * two kernels (with the GEMM/norm/embedding entry points above) make one step a fixed chain.
  * gct_attn_decode: ONE query row per (sample, head): q [n][H*dk] (ld ldq); keys/values row j of
  * sample b at k + b*kv_batch + j*kv_row (+ h*dk); valid (nullable) uint8 [n][>=Lc], 0 => -1e9;
- * o [n][H*dk].  Lc <= 256. */
-int gct_attn_decode(const float* q, int64_t ldq, const float* k, const float* v, int64_t kv_row,
+ * o [n][H*dk].  Lc <= 256.
+ * pos (nullable) = DEVICE-side step counter: the caches hold cache_off + *pos keys, and this step's own key / value
+ * (row b of knew / vnew, leading dimension ldn) are appended at that row and attended to -- one captured graph then
+ * serves every step of the loop (gct_decode_embed / gct_select_token read the same counter, gct_decode_advance
+ * increments it at the end of the step).  With pos == NULL the first Lc cached keys are used as they are. */
+int gct_attn_decode(const float* q, int64_t ldq, float* k, float* v, int64_t kv_row,
                     int64_t kv_batch, const uint8_t* valid, int64_t valid_sb, float* o, int64_t ldo,
-                    int n, int H, int Lc, int dk, float scale, void* stream);
+                    int n, int H, int Lc, int dk, float scale, const int32_t* pos, int cache_off,
+                    const float* knew, const float* vnew, int64_t ldn, void* stream);
+/* x[b] = table[ys[b][*pos]] * scale + pe[pe_off + *pos] (Embeddings + PositionalEncoding of one position, eval mode) */
+int gct_decode_embed(const int64_t* ys, int64_t ld_ys, const int32_t* pos, int pe_off, const float* table,
+                     int vocab, const float* pe, float* out, int n, int d, float scale, void* stream);
+int gct_decode_advance(int32_t* pos, void* stream);
 /* softmax(logits[n][V]) then mode 0: argmax (first maximum, torch.max semantics) / mode 1:
- * multinomial (Philox inverse-CDF).  Writes ys[row*ld_ys + pos], valid[row*valid_sb + pos] =
- * (token != pad), done[row] |= (token == eos); probs_out (nullable) [n][V]. */
+ * multinomial (Philox inverse-CDF).  Writes ys[row*ld_ys + pos], valid[row*valid_sb + valid_off + pos] =
+ * (token != pad), done[row] |= (token == eos); probs_out (nullable) [n][V].  pos_dev (nullable): pos = *pos_dev + 1;
+ * seed_dev (nullable): the multinomial seed is read from device memory (graph replays with a fresh seed). */
 int gct_select_token(const float* logits, int V, int64_t* ys, int64_t ld_ys, int pos, uint8_t* valid,
                      int64_t valid_sb, uint8_t* done, float* probs_out, int n, int mode,
-                     int64_t pad_id, int64_t eos_id, uint64_t seed, void* stream);
+                     int64_t pad_id, int64_t eos_id, uint64_t seed, const int32_t* pos_dev, int valid_off,
+                     const uint64_t* seed_dev, void* stream);
 
 /* ------------------------------------------------ host side: SMILES tokeniser + collate */
 /* Utils/field.py:8-33 moltokenize (the atom-wise regex, findall semantics) as a scanner.

@@ -37,7 +37,7 @@ def test_kv_decode_matches_reference_golden_ids(golden_dir):
         assert torch.allclose(kd.buf["logits"].cpu(), fx["last_logits"], atol=1e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("mtype,graphs", [("vaetf", False), ("pscavaetf", False), ("vaetf", True)])
+@pytest.mark.parametrize("mtype,graphs", [("vaetf", False), ("pscavaetf", False), ("vaetf", True), ("pscavaetf", True)])
 def test_kv_decode_matches_uncached_full_size(mtype, graphs):
     """Full-size model, ragged source masks, a scaffold-style prefix for pscavaetf, early <eos> stop."""
     from gct_plus_amd.decode import KVDecoder, reference_style_decode
@@ -144,3 +144,62 @@ def test_kv_decode_long_scaffold_prefix():
     kd.start(z, src_mask, dconds, max_total_len=176)
     ys = kd.generate(ys0, max_strlen=50)
     assert ys.shape[1] == 169 and torch.equal(ys, ref)
+
+
+def build_c2d(mtype="pvaetf", seed=2):
+    from gct_plus_amd.Model import model_dict
+    vs, vt = synthetic.vocab_sizes(mtype)
+    torch.manual_seed(seed)
+    return model_dict[mtype](vs, vt, dropout=0.1, nconds=3, use_cond2dec=True, use_cond2lat=False, **TINY).cuda().eval()
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_kv_decode_use_cond2dec(graphs):
+    """-use_cond2dec (reference Model/vaetf.py:83-86, Model/modules.py:19-26, Inference/sampling_tool.py:151-160): the
+    n_c condition tokens sit in front of the decoder stream, see each other and the first token; the cached decoder
+    prefills them with the prefix and must reproduce the un-cached reference-style loop token for token."""
+    from gct_plus_amd.decode import KVDecoder, reference_style_decode
+    from gct_plus_amd.Model.modules import get_trg_mask
+    model = build_c2d()
+    n, Le = 7, 19
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(n, Le, TINY["latent_dim"], generator=g).cuda()
+    dconds = torch.randn(n, 3, generator=g).cuda()
+    lens = torch.randint(8, Le + 1, (n,), generator=g)
+    src_mask = (torch.arange(Le)[None, :] < lens[:, None]).unsqueeze(1).cuda()
+    ys0 = torch.full((n, 1), synthetic.SOS_ID, dtype=torch.long, device="cuda")
+    # the reference-style loop for cond2dec: block mask, logits of the token rows only
+    ys = ys0.clone()
+    for _ in range(29):
+        tm = get_trg_mask(ys, synthetic.PAD_ID, True, dconds)
+        logits = model.decode(ys, z, src_mask, tm, dconds)[:, 3:]
+        ys = torch.cat([ys, logits[:, -1].argmax(-1)[:, None]], dim=1)
+    kd = KVDecoder(model, synthetic.PAD_ID, synthetic.SOS_ID, -1)
+    kd.start(z, src_mask, dconds, max_total_len=40)
+    out = kd.generate(ys0, max_strlen=30, use_graphs=graphs)
+    assert torch.equal(out, ys)
+
+
+def test_graph_replay_survives_restarts_with_other_shapes():
+    """ADVICE r1 (decode.py): graphs are captured against the decoder's buffers.  A second sample call with another
+    batch size reallocates them -- the stale graphs must go (they hold raw pointers); with the same geometry they are
+    reused; the multinomial seed is read from device memory, so a new seed needs no new graph."""
+    from gct_plus_amd.decode import KVDecoder
+    model = build("scavaetf")
+    kd_g = KVDecoder(model, synthetic.PAD_ID, synthetic.SOS_ID, synthetic.EOS_ID)
+    kd_e = KVDecoder(model, synthetic.PAD_ID, synthetic.SOS_ID, synthetic.EOS_ID)
+    g = torch.Generator().manual_seed(9)
+    ngraphs = []
+    for call, (n, Le, t0) in enumerate([(6, 14, 5), (6, 14, 5), (11, 20, 3), (6, 14, 5)]):
+        z = torch.randn(n, Le, TINY["latent_dim"], generator=g).cuda()
+        src_mask = torch.ones(n, 1, Le, dtype=torch.bool, device="cuda")
+        pre = torch.randint(5, 30, (n, t0 - 1), generator=g)
+        ys0 = torch.cat([torch.full((n, 1), synthetic.SOS_ID), pre], 1).cuda()
+        for algo in ("greedy", "multinomial"):
+            outs = []
+            for kd, graphs in ((kd_g, True), (kd_e, False)):
+                kd.start(z, src_mask, None, max_total_len=40)
+                outs.append(kd.generate(ys0, max_strlen=20, algo=algo, seed=100 + call, use_graphs=graphs))
+            assert outs[0].shape == outs[1].shape and torch.equal(outs[0], outs[1]), (call, algo)
+        ngraphs.append(len(kd_g.graphs))
+    assert ngraphs == [2, 2, 2, 2]          # one graph per selection mode, re-captured only when the geometry changed
