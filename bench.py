@@ -62,7 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the short fp32-MFMA-mode comparison run")
     ap.add_argument("--no-fixed-len-leg", action="store_true", help="skip the short fixed_len_80 region")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode block (configs[4] metric)")
-    ap.add_argument("--decode-n", type=int, default=512)
+    ap.add_argument("--decode-n", type=int, default=4096, help="sequences decoded per GPU (the sampler's n is a free parameter)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo only for the launcher tests")
     ap.add_argument("--share-gpu", action="store_true",

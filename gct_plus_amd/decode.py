@@ -89,8 +89,11 @@ class KVDecoder:
             dff = dec.layers[0].ff.linear_1.weight.shape[0]
             V = self.model.out.weight.shape[0]
             wsb = max(ops._L().gct_linear_fwd_ws_bytes(n, dff, d), ops._L().gct_linear_fwd_ws_bytes(n, d, 3 * d),
-                      ops._L().gct_linear_fwd_ws_bytes(n, d, dff))
-            self.ws = torch.empty(wsb // 4 + 64, device=dev)           # split-K slabs of the skinny GEMMs
+                      ops._L().gct_linear_fwd_ws_bytes(n, d, dff), ops._L().gct_linear_fwd_ws_bytes(n, d, d),
+                      ops._L().gct_linear_fwd_ws_bytes(n, d, V))
+            self.ws = torch.empty(wsb // 4 + 64, device=dev)           # split-K / tail slabs of the step's GEMMs
+            # few rows: the skinny split-K kernels; many rows (n >= 1024): the general path, i.e. the bf16x6 kernels
+            self.gemm_kw = dict(splitk_ws=self.ws) if n < 1024 else dict(ws=self.ws)
             f = lambda *sh: torch.empty(*sh, device=dev)                # noqa: E731
             self.buf = dict(x=f(n, d), x2=f(n, d), qkv=f(n, 3 * d), o=f(n, d), xa=f(n, d), q2=f(n, d), o2=f(n, d),
                             xb=f(n, d), pre=f(n, dff), hdn=f(n, dff), xc=[f(n, d), f(n, d)], y=f(n, d),
@@ -149,29 +152,29 @@ class KVDecoder:
             qkv = B["qkv"]
             ops.linear_fwd(B["x2"], [a1.q_linear.weight, a1.k_linear.weight, a1.v_linear.weight],
                            [a1.q_linear.bias, a1.k_linear.bias, a1.v_linear.bias],
-                           [qkv, qkv[:, d:], qkv[:, 2 * d:]], 3 * d, splitk_ws=self.ws)
+                           [qkv, qkv[:, d:], qkv[:, 2 * d:]], 3 * d, **self.gemm_kw)
             ops.attn_decode(qkv, 3 * d, self.kc[li], self.vc[li], d, T * d, self.valid, T, B["o"], n,
                             self.H, 0, self.dk, pos=self.pos, cache_off=self.off, knew=qkv[:, d:],
                             vnew=qkv[:, 2 * d:], ldn=3 * d)
             ops.linear_fwd(B["o"], [a1.out.weight], [a1.out.bias], [B["xa"]], d,
-                           epi=ops.EPI_DROP_RESID, resid=x, splitk_ws=self.ws)
+                           epi=ops.EPI_DROP_RESID, resid=x, **self.gemm_kw)
             ops.norm_fwd(B["xa"], layer.norm_2.alpha, layer.norm_2.bias, layer.norm_2.eps, out=B["x2"])
-            ops.linear_fwd(B["x2"], [a2.q_linear.weight], [a2.q_linear.bias], [B["q2"]], d, splitk_ws=self.ws)
+            ops.linear_fwd(B["x2"], [a2.q_linear.weight], [a2.q_linear.bias], [B["q2"]], d, **self.gemm_kw)
             kv = self.cross_kv[li]
             ops.attn_decode(B["q2"], d, kv, kv[:, d:], 2 * d, self.Lk * 2 * d, self.src_valid, self.Lk,
                             B["o2"], n, self.H, self.Lk, self.dk)
             ops.linear_fwd(B["o2"], [a2.out.weight], [a2.out.bias], [B["xb"]], d,
-                           epi=ops.EPI_DROP_RESID, resid=B["xa"], splitk_ws=self.ws)
+                           epi=ops.EPI_DROP_RESID, resid=B["xa"], **self.gemm_kw)
             ops.norm_fwd(B["xb"], layer.norm_3.alpha, layer.norm_3.bias, layer.norm_3.eps, out=B["x2"])
             ops.linear_fwd(B["x2"], [ff.linear_1.weight], [ff.linear_1.bias], [B["hdn"]],
-                           B["hdn"].shape[1], epi=ops.EPI_GELU_DROP, pre=B["pre"], splitk_ws=self.ws)
+                           B["hdn"].shape[1], epi=ops.EPI_GELU_DROP, pre=B["pre"], **self.gemm_kw)
             xc = B["xc"][li & 1]
             ops.linear_fwd(B["hdn"], [ff.linear_2.weight], [ff.linear_2.bias], [xc], d,
-                           epi=ops.EPI_DROP_RESID, resid=B["xb"], splitk_ws=self.ws)
+                           epi=ops.EPI_DROP_RESID, resid=B["xb"], **self.gemm_kw)
             x = xc
         ops.norm_fwd(x, dec.norm.alpha, dec.norm.bias, dec.norm.eps, out=B["y"])
         out = self.model.out
-        ops.linear_fwd(B["y"], [out.weight], [out.bias], [B["logits"]], out.weight.shape[0])
+        ops.linear_fwd(B["y"], [out.weight], [out.bias], [B["logits"]], out.weight.shape[0], ws=self.ws)
         return B["logits"]
 
     def _select(self, mode):
