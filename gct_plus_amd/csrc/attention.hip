@@ -61,6 +61,10 @@ struct AttnArgs {
   // nlive[b] query rows exist; kv_compact: dk / dv (self-attention) live in the same compact rows
   const int32_t *cstart, *nlive;
   int kv_compact;
+  // compacted keys / values (cross-attention over the encoder memory without its padded rows): the K / V rows of
+  // sample b start at kstart[b] and only its first klen[b] keys exist (the rest are masked keys: zero rows in LDS);
+  // the backward's dk / dv live in the same rows
+  const int32_t *kstart, *klen;
   int B, H, Lq, Lk, npairs;
   float scale, keep_scale;
   uint32_t thr;
@@ -379,8 +383,9 @@ __global__ __launch_bounds__(ATT_THREADS, OCC) void attn_fwd_kernel(const AttnAr
   uint4 mraw[(MW + 3) / 4] = {};
   {
     const int b = pair / a.H, h = pair - b * a.H;
-    sk.load(a.k, a.ldk, b, h, a.Lk, kvo);
-    sv.load(a.v, a.ldv, b, h, a.Lk, kvo);
+    const int64_t kr0 = a.kstart ? (int64_t)a.kstart[b] : (int64_t)b * a.Lk;
+    sk.load_rows(a.k, a.ldk, kr0, h, kvo);
+    sv.load_rows(a.v, a.ldv, kr0, h, kvo);
     row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, 16 * wave + c16, g);
     if (a.mbits) mask_row_raw<MW>(mraw, a, b, 16 * wave + c16);
   }
@@ -388,8 +393,9 @@ __global__ __launch_bounds__(ATT_THREADS, OCC) void attn_fwd_kernel(const AttnAr
   for (;;) {
     const int b = pair / a.H, h = pair - b * a.H;
     ASTAMP(0);                           // loop seam
-    sk.store(Ks, a.Lk, LKP, tid);
-    sv.store(Vs, a.Lk, LKP, tid);
+    const int Lk_in = a.klen ? a.klen[b] : a.Lk;          // keys that exist as rows (the others are masked: zero rows)
+    sk.store(Ks, Lk_in, LKP, tid);
+    sv.store(Vs, Lk_in, LKP, tid);
     uint32_t mw[MW];
     mask_row_use<MW>(mw, mraw, a, 16 * wave + c16);
     ASTAMP(1);                           // wait for the staged K / V + LDS stores
@@ -400,9 +406,10 @@ __global__ __launch_bounds__(ATT_THREADS, OCC) void attn_fwd_kernel(const AttnAr
     const int nb = more ? next / a.H : b, nh = more ? next - nb * a.H : h;
     // Next pair's operands: requested now, consumed at the top of the next iteration.  NOTHING loaded below this
     // point may be consumed before then (a wait on a younger load waits for these too).
+    const int64_t nkr0 = a.kstart ? (int64_t)a.kstart[nb] : (int64_t)nb * a.Lk;
     if (PIPE && more) {
-      sk.load(a.k, a.ldk, nb, nh, a.Lk, kvo);
-      sv.load(a.v, a.ldv, nb, nh, a.Lk, kvo);
+      sk.load_rows(a.k, a.ldk, nkr0, nh, kvo);
+      sv.load_rows(a.v, a.ldv, nkr0, nh, kvo);
       if (a.mbits) mask_row_raw<MW>(mraw, a, nb, 16 * wave + c16);
     }
     ASTAMP(3);                           // prefetch issue
@@ -425,8 +432,8 @@ __global__ __launch_bounds__(ATT_THREADS, OCC) void attn_fwd_kernel(const AttnAr
     __syncthreads();                     // every wave is done reading Ks / Vs
     ASTAMP(5);                           // barrier 2
     if (!PIPE) {
-      sk.load(a.k, a.ldk, nb, nh, a.Lk, kvo);
-      sv.load(a.v, a.ldv, nb, nh, a.Lk, kvo);
+      sk.load_rows(a.k, a.ldk, nkr0, nh, kvo);
+      sv.load_rows(a.v, a.ldv, nkr0, nh, kvo);
       row_frag_global<NDT>(bq, a.q, a.ldq, nb, nh, a.Lq, 16 * wave + c16, g);
       if (a.mbits) mask_row_raw<MW>(mraw, a, nb, 16 * wave + c16);
     }
@@ -460,8 +467,10 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
     const int64_t lrow0 = ((int64_t)b * a.H + h) * a.Lq;
     const int Lq_e = a.nlive ? a.nlive[b] : a.Lq;                               // query rows that exist in dout / dq
     const int64_t drow0 = a.cstart ? (int64_t)a.cstart[b] : (int64_t)b * a.Lq;  // row of (b, 0) in dout / dq
-    const int Lk_e = a.kv_compact ? Lq_e : a.Lk;                                // key rows that exist in dk / dv
-    const int64_t krow0 = a.kv_compact ? drow0 : (int64_t)b * a.Lk;
+    const int64_t kin0 = a.kstart ? (int64_t)a.kstart[b] : (int64_t)b * a.Lk;   // row of key 0 in k / v
+    const int Lk_in = a.klen ? a.klen[b] : a.Lk;                                // keys that exist as rows of k / v
+    const int Lk_e = a.kv_compact ? Lq_e : Lk_in;                               // key rows that exist in dk / dv
+    const int64_t krow0 = a.kv_compact ? drow0 : kin0;
     // ---------------------------------------------------------------- phase A: K, V in LDS -> dQ
     // every global load of this phase is issued up front: this wave's Q / dO / O rows and lse ride along with the
     // K / V staging loads, so the MFMAs below start with everything on chip
@@ -473,8 +482,8 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
     float lse0 = a.lse_in[lrow0 + (q0 < a.Lq ? q0 : a.Lq - 1)];
     {
       Stage<DK, NT> sk, sv;
-      sk.load(a.k, a.ldk, b, h, a.Lk, kvo);
-      sv.load(a.v, a.ldv, b, h, a.Lk, kvo);
+      sk.load_rows(a.k, a.ldk, kin0, h, kvo);
+      sv.load_rows(a.v, a.ldv, kin0, h, kvo);
       // packed mask rows and "row sees a key" (both phases read them from LDS)
       for (int q = tid; q < LQP; q += ATT_THREADS) {
         uint4 raw[(MW + 3) / 4] = {};
@@ -489,8 +498,8 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
         }
         rowok[q] = (q >= a.Lq) || vis != 0;
       }
-      sk.store(R0, a.Lk, LKP, tid);
-      sv.store(R1, a.Lk, LKP, tid);
+      sk.store(R0, Lk_in, LKP, tid);
+      sv.store(R1, Lk_in, LKP, tid);
     }
     __syncthreads();
     float4 bk[NDT], bv[NDT];
@@ -628,8 +637,8 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
       dof.init(a.ldo, a.Lq, tid);
       sq.load(a.q, a.ldq, b, h, a.Lq, qo);           // second read of this pair's Q / dO: L2
       sd.load_rows(a.dout, a.ldo, drow0, h, dof);    // (rows beyond Lq_e belong to other samples: zeroed by store)
-      row_frag_global<NDT>(bk, a.k, a.ldk, b, h, a.Lk, 16 * wave + c16, g);
-      row_frag_global<NDT>(bv, a.v, a.ldv, b, h, a.Lk, 16 * wave + c16, g);
+      row_frag_rows<NDT>(bk, a.k, a.ldk, kin0, h, Lk_in, 16 * wave + c16, g);
+      row_frag_rows<NDT>(bv, a.v, a.ldv, kin0, h, Lk_in, 16 * wave + c16, g);
       sq.store(R0, Lq_e, LQP, tid);
       sd.store(R1, Lq_e, LQP, tid);
     }
@@ -638,8 +647,8 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
       const int k = 16 * t + c16;
       if (16 * t >= Lk_e) continue;        // compact self-attention: dead keys have no row (and no gradient)
       if (t != wave) {
-        row_frag_global<NDT>(bk, a.k, a.ldk, b, h, a.Lk, k, g);
-        row_frag_global<NDT>(bv, a.v, a.ldv, b, h, a.Lk, k, g);
+        row_frag_rows<NDT>(bk, a.k, a.ldk, kin0, h, Lk_in, k, g);
+        row_frag_rows<NDT>(bv, a.v, a.ldv, kin0, h, Lk_in, k, g);
       }
       f32x4 vacc[NDT], kacc[NDT];
 #pragma unroll
@@ -822,7 +831,7 @@ extern "C" int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t
                             const float* v, int64_t ldv, const uint32_t* mbits, int64_t mb_sb,
                             int64_t mb_sq, float* o, int64_t ldo, float* lse, float* probs, int B,
                             int H, int Lq, int Lk, int dk, float scale, float p, uint64_t seed,
-                            uint32_t site, void* stream) {
+                            uint32_t site, const int32_t* kstart, const int32_t* klen, void* stream) {
   int rc = check_common("attn_fwd", q, ldq, k, ldk, v, ldv, mbits, mb_sb, mb_sq, B, H, Lq, Lk, dk, p);
   if (rc) return rc;
   GCT_CHECK_ARG(o && lse && ldo % 4 == 0 && gct_aligned16(o) && (int64_t)Lq * ldo * 4 < (1ll << 31), "attn_fwd: bad output");
@@ -831,6 +840,8 @@ extern "C" int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t
   a.q = q; a.k = k; a.v = v; a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv;
   a.mbits = mbits; a.mb_sb = (int)mb_sb; a.mb_sq = (int)mb_sq;
   a.o = o; a.ldo = (int)ldo; a.lse = lse; a.probs = probs;
+  GCT_CHECK_ARG((kstart == nullptr) == (klen == nullptr), "attn_fwd: kstart / klen go together");
+  a.kstart = kstart; a.klen = klen;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.npairs = B * H; a.scale = scale;
   a.thr = gct_drop_threshold(p); a.keep_scale = 1.0f / (1.0f - p); a.rng = gct_rng_make(seed, site);
   const int LQP = (Lq + 15) & ~15, LKP = (Lk + 15) & ~15, SD = dk + 4;
@@ -851,7 +862,8 @@ extern "C" int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t
                             const float* lse, float* dq, int64_t lddq, float* dk_,
                             int64_t lddk, float* dv, int64_t lddv, int B, int H, int Lq, int Lk,
                             int dk, float scale, float p, uint64_t seed, uint32_t site,
-                            const int32_t* cstart, const int32_t* nlive, int kv_compact, void* stream) {
+                            const int32_t* cstart, const int32_t* nlive, int kv_compact,
+                            const int32_t* kstart, const int32_t* klen, void* stream) {
   int rc = check_common("attn_bwd", q, ldq, k, ldk, v, ldv, mbits, mb_sb, mb_sq, B, H, Lq, Lk, dk, p);
   if (rc) return rc;
   GCT_CHECK_ARG(o && dout && lse && dq && dk_ && dv, "attn_bwd: null pointer");
@@ -870,6 +882,9 @@ extern "C" int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t
   GCT_CHECK_ARG((cstart == nullptr) == (nlive == nullptr) && (!kv_compact || (cstart && Lq == Lk)),
                 "attn_bwd: cstart / nlive go together; kv_compact needs them and Lq == Lk");
   a.cstart = cstart; a.nlive = nlive; a.kv_compact = kv_compact;
+  GCT_CHECK_ARG((kstart == nullptr) == (klen == nullptr) && !(kstart && kv_compact),
+                "attn_bwd: kstart / klen go together and exclude kv_compact");
+  a.kstart = kstart; a.klen = klen;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.npairs = B * H; a.scale = scale;
   a.thr = gct_drop_threshold(p); a.keep_scale = 1.0f / (1.0f - p); a.rng = gct_rng_make(seed, site);
   const int LQP = (Lq + 15) & ~15, LKP = (Lk + 15) & ~15, SD = dk + 4;

@@ -267,6 +267,53 @@ extern "C" int gct_live_rows(const float* g, int64_t ld, int B, int T, int cols,
   return GCT_OK;
 }
 
+// Key rows of a key-padding mask [B][Lk]: live = mask != 0; n_b; info[0] live keys, info[2] samples whose visible
+// keys are not the prefix 0..n_b-1, info[6] samples without a visible key.  One wave per sample.
+__global__ __launch_bounds__(256) void key_flags_kernel(const uint8_t* __restrict__ mask, int64_t sb, int B, int Lk,
+                                                        uint8_t* __restrict__ live, int32_t* __restrict__ n_b,
+                                                        int32_t* __restrict__ info) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const uint8_t* m = mask + (int64_t)b * sb;
+  int cnt = 0, nonpre = 0;
+  for (int k = lane; k < Lk; k += 64) {
+    const int f = m[k] != 0;
+    live[(int64_t)b * Lk + k] = (uint8_t)f;
+    cnt += f;
+    if (k + 1 < Lk && !f && m[k + 1] != 0) nonpre = 1;
+  }
+  cnt = (int)gct_wave_sum((float)cnt);
+  nonpre = __any(nonpre);
+  if (lane == 0) {
+    n_b[b] = cnt;
+    atomicAdd(&info[0], cnt);
+    if (nonpre) atomicAdd(&info[2], 1);
+    if (cnt == 0) atomicAdd(&info[6], 1);
+  }
+}
+
+extern "C" int gct_key_rows(const uint8_t* mask, int64_t mask_sb, int B, int Lk, uint8_t* live, int32_t* n_b,
+                            int32_t* info, int32_t* cstart, int32_t* quad_list, int32_t* qrank_ws, void* stream) {
+  GCT_CHECK_ARG(mask && live && n_b && info && cstart && quad_list && qrank_ws && B >= 0 && Lk > 0 && mask_sb >= Lk,
+                "key_rows: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(info, 0, 8 * sizeof(int32_t), st);
+  if (e != hipSuccess) {
+    gct_set_error("key_rows: memset failed: %s", hipGetErrorString(e));
+    return GCT_ERR_HIP;
+  }
+  if (B > 0) {
+    hipLaunchKernelGGL(key_flags_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, mask, mask_sb, B, Lk, live, n_b,
+                       info);
+    GCT_LAUNCH_CHECK("key_flags");
+  }
+  hipLaunchKernelGGL(live_quads_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)live, B, Lk, quad_list, qrank_ws,
+                     cstart, info);
+  GCT_LAUNCH_CHECK("live_quads");
+  return GCT_OK;
+}
+
 extern "C" int gct_gather_quads(const float* src, int64_t ld, int64_t M, const int32_t* quad_list, int64_t nrows,
                                 int cols, float* dst, int64_t ldd, void* stream) {
   GCT_CHECK_ARG(src && quad_list && dst && nrows >= 0 && nrows % 4 == 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 &&

@@ -30,6 +30,8 @@ _SEED = {"base": None, "ctr": 0}
 # when the compact rows are at most this fraction of all rows (the gathers cost ~1 ms per step).
 COMPACT_BWD = os.environ.get("GCT_COMPACT_BWD", "1") != "0"
 COMPACT_MAX_FRACTION = 0.85
+# Cross-attention over the visible rows of the encoder memory only (decoder_trunk_fwd): GCT_COMPACT_KV=0 disables.
+COMPACT_KV = os.environ.get("GCT_COMPACT_KV", "1") != "0"
 
 
 def next_seed() -> int:
@@ -94,7 +96,7 @@ def _empty(rows, cols, like):
 
 
 # ------------------------------------------------------------------------------------- MHA
-def mha_fwd(run: Run, m, xq, xkv, B, Lq, Lk, mask_u8, resid, want_probs=False):
+def mha_fwd(run: Run, m, xq, xkv, B, Lq, Lk, mask_u8, resid, want_probs=False, keys=None):
     """m: MultiHeadAttention module (q_linear, k_linear, v_linear, out).  xq [B*Lq,d],
     xkv [B*Lk,d] (the same tensor object for self-attention).  With `resid` the output
     projection fuses  resid + dropout(.)  (the layer's dropout_k + residual add)."""
@@ -111,13 +113,14 @@ def mha_fwd(run: Run, m, xq, xkv, B, Lq, Lk, mask_u8, resid, want_probs=False):
     else:
         qb = _empty(B * Lq, d, xq)
         ops.linear_fwd(xq, [m.q_linear.weight], [m.q_linear.bias], [qb], d)
-        kvb = _empty(B * Lk, 2 * d, xkv)
+        # keys (ops.KeyRows): xkv holds the VISIBLE rows of the encoder memory only (quad-compacted)
+        kvb = _empty(B * Lk, 2 * d, xkv) if keys is None else keys.empty(2 * d)
         ops.linear_fwd(xkv, [m.k_linear.weight, m.v_linear.weight],
                        [m.k_linear.bias, m.v_linear.bias], [kvb, kvb[:, d:]], 2 * d)
         q, k, v, ldq, ldkv = qb, kvb, kvb[:, d:], d, 2 * d
     site_p = run.site()
     o, lse, probs = ops.attn_fwd(q, k, v, ldq, ldkv, ldkv, mask_u8, B, H, Lq, Lk, dk, run.p,
-                                 run.seed, site_p, want_probs=want_probs)
+                                 run.seed, site_p, want_probs=want_probs, keys=keys)
     y = _empty(B * Lq, d, xq)
     site_o = run.site()
     if resid is not None:
@@ -125,7 +128,7 @@ def mha_fwd(run: Run, m, xq, xkv, B, Lq, Lk, mask_u8, resid, want_probs=False):
                        resid=resid, p=run.p, seed=run.seed, site=site_o)
     else:
         ops.linear_fwd(o, [m.out.weight], [m.out.bias], [y], d)
-    saved = (xq, xkv, qb, kvb, o, lse, mask_u8, B, Lq, Lk, site_p, site_o, resid is not None)
+    saved = (xq, xkv, qb, kvb, o, lse, mask_u8, B, Lq, Lk, site_p, site_o, resid is not None, keys)
     return y, saved, probs
 
 
@@ -136,10 +139,10 @@ def mha_bwd(run: Run, m, saved, dy, G: GradSink, dxq_out, depi_q, dxkv_out=None,
     d(xkv) into dxkv_out (epilogue depi_kv).  The identity path to `resid` is the caller's.
     live (ops.LiveRows): the QUERY-side rows (dy, dxq_out) are quad-compacted; saved forward tensors are
     gathered on the way in, key/value-side gradients of cross-attention stay in the encoder's row space."""
-    xq, xkv, qb, kvb, o, lse, mask_u8, B, Lq, Lk, site_p, site_o, fused = saved
+    xq, xkv, qb, kvb, o, lse, mask_u8, B, Lq, Lk, site_p, site_o, fused, keys = saved
     d, H = m.d_model, m.h
     dk = d // H
-    Mq, Mk = B * Lq, B * Lk
+    Mq, Mk = B * Lq, xkv.shape[0]
     kt = run.kt
     new = lambda cols: _empty(Mq, cols, dy)                                      # noqa: E731
     if live is not None:
@@ -167,9 +170,12 @@ def mha_bwd(run: Run, m, saved, dy, G: GradSink, dxq_out, depi_q, dxkv_out=None,
                          depi=depi_q)
     else:
         dq = new(d)
-        dkv = _empty(Mk, 2 * d, dy)
+        if keys is None:
+            dkv = _empty(Mk, 2 * d, dy)
+        else:      # compacted keys: the rows that pad a quad belong to no sample and are never written
+            dkv = torch.zeros(keys.Mc + keys.SLACK, 2 * d, dtype=torch.float32, device=dy.device)[:keys.Mc]
         ops.attn_bwd(qb, kvb, kvb[:, d:], d, 2 * d, 2 * d, mask_u8, o, do, lse, dq, dkv, dkv[:, d:],
-                     d, 2 * d, 2 * d, B, H, Lq, Lk, dk, run.p, run.seed, site_p, live=live)
+                     d, 2 * d, 2 * d, B, H, Lq, Lk, dk, run.p, run.seed, site_p, live=live, keys=keys)
         ops.linear_wgrad([dq], d, xq_in, [G(m.q_linear.weight)], [G(m.q_linear.bias)], kt=kt)   # query rows
         ops.linear_wgrad([dkv, dkv[:, d:]], 2 * d, xkv,
                          [G(m.k_linear.weight), G(m.v_linear.weight)],
@@ -239,11 +245,11 @@ def enc_layer_bwd(run: Run, layer, saved, g, G: GradSink):
     return g
 
 
-def dec_layer_fwd(run: Run, layer, x, e, B, T, Lk, src_mask_u8, trg_mask_u8, want_probs=False):
+def dec_layer_fwd(run: Run, layer, x, e, B, T, Lk, src_mask_u8, trg_mask_u8, want_probs=False, keys=None):
     x2, m1, r1 = ops.norm_fwd(x, layer.norm_1.alpha, layer.norm_1.bias, layer.norm_1.eps)
     xa, sv1, p1 = mha_fwd(run, layer.attn_1, x2, x2, B, T, T, trg_mask_u8, x, want_probs)
     x2, m2, r2 = ops.norm_fwd(xa, layer.norm_2.alpha, layer.norm_2.bias, layer.norm_2.eps)
-    xb, sv2, p2 = mha_fwd(run, layer.attn_2, x2, e, B, T, Lk, src_mask_u8, xa, want_probs)
+    xb, sv2, p2 = mha_fwd(run, layer.attn_2, x2, e, B, T, Lk, src_mask_u8, xa, want_probs, keys=keys)
     x2, m3, r3 = ops.norm_fwd(xb, layer.norm_3.alpha, layer.norm_3.bias, layer.norm_3.eps)
     xc, svf = ffn_fwd(run, layer.ff, x2, xb)
     return xc, (x, m1, r1, sv1, xa, m2, r2, sv2, xb, m3, r3, svf), p1, p2
@@ -345,21 +351,34 @@ def decoder_trunk_fwd(dec, run: Run, trg, z, src_mask_u8, trg_mask_u8, dconds, w
             ones = torch.ones(B, nc, dtype=torch.uint8, device=src_mask_u8.device)
             src_mask_u8 = torch.cat([ones, src_mask_u8.view(B, Le)], dim=1).contiguous()
     lsv, p1s, p2s = [], [], []
+    # Padded rows of the encoder memory are masked keys of every cross-attention: their K / V projections are never
+    # used and their dK / dV are zero.  When src_mask is a key-padding mask whose visible keys form a prefix of
+    # every sample (device check, one 32-byte read-back), the six K|V GEMMs, their weight gradients and the
+    # gradient w.r.t. the memory run on the visible rows only (quad-compacted, ops.KeyRows).
+    keys = None
+    if (COMPACT_KV and src_mask_u8 is not None and src_mask_u8.numel() == B * Lk and len(dec.layers) > 0
+            and not torch.cuda.is_current_stream_capturing()):
+        kr = ops.KeyRows(src_mask_u8.view(B, Lk), B, Lk)
+        h = kr.host()
+        if h["nonprefix"] == 0 and h["empty"] == 0 and 0 < h["padded"] <= COMPACT_MAX_FRACTION * B * Lk:
+            keys = kr
+            e = keys.gather(e)
     src_m = ops.pack_mask(src_mask_u8, B, T, Lk)
     trg_m = ops.pack_mask(trg_mask_u8, B, T, T)
     for layer in dec.layers:
-        x, sv, p1, p2 = dec_layer_fwd(run, layer, x, e, B, T, Lk, src_m, trg_m, want_probs)
+        x, sv, p1, p2 = dec_layer_fwd(run, layer, x, e, B, T, Lk, src_m, trg_m, want_probs, keys=keys)
         lsv.append(sv)
         p1s.append(p1)
         p2s.append(p2)
     y, mean, rstd = ops.norm_fwd(x, dec.norm.alpha, dec.norm.bias, dec.norm.eps)
     saved = (trg, z2, dconds, site_pe, lsv, x, mean, rstd, B, T, Le, Lk, c2d, c2l,
-             trg_mask_u8.u8 if isinstance(trg_mask_u8, ops.MaskBits) else trg_mask_u8)
+             trg_mask_u8.u8 if isinstance(trg_mask_u8, ops.MaskBits) else trg_mask_u8, keys)
     return y.view(B, T, d), saved, p1s, p2s
 
 
 def decoder_trunk_bwd(dec, run: Run, saved, dy, G: GradSink, need_dz=True):
-    trg, z2, dconds, site_pe, lsv, x_last, mean, rstd, B, T, Le, Lk, c2d, c2l, trg_mask_u8 = saved
+    trg, z2, dconds, site_pe, lsv, x_last, mean, rstd, B, T, Le, Lk, c2d, c2l, trg_mask_u8, keys = saved
+    new_de = (lambda: _empty(B * Lk, d, dy)) if keys is None else (lambda: keys.empty(d))     # d(memory), maybe compact
     d, nc = dec.d_model, dec.nconds
     # A decoder row whose incoming gradient is zero (padded target positions under the ignore_index loss: 56 % of
     # the rows at MOSES-like lengths) keeps a zero gradient through every layer below -- norm, linear, GELU and
@@ -380,7 +399,7 @@ def decoder_trunk_bwd(dec, run: Run, saved, dy, G: GradSink, need_dz=True):
         gc = live.gather(g)
         ops.norm_bwd(gc, x_last, dec.norm.alpha, mean, rstd, G(dec.norm.alpha), G(dec.norm.bias), out=gc,
                      eps=dec.norm.eps, live=live)
-        de = _empty(B * Lk, d, g)
+        de = new_de()
         first = True
         for layer, sv in zip(reversed(dec.layers), reversed(lsv)):
             gc = dec_layer_bwd(run, layer, sv, gc, de, first, G, live=live)
@@ -391,7 +410,7 @@ def decoder_trunk_bwd(dec, run: Run, saved, dy, G: GradSink, need_dz=True):
         run.kt = lr.kt if (lr is not None and (B * T) % 32 == 0) else None
         ops.norm_bwd(g, x_last, dec.norm.alpha, mean, rstd, G(dec.norm.alpha), G(dec.norm.bias), out=g,
                      eps=dec.norm.eps)
-        de = _empty(B * Lk, d, g)
+        de = new_de()
         first = True
         for layer, sv in zip(reversed(dec.layers), reversed(lsv)):
             g = dec_layer_bwd(run, layer, sv, g, de, first, G)
@@ -399,6 +418,8 @@ def decoder_trunk_bwd(dec, run: Run, saved, dy, G: GradSink, need_dz=True):
         run.kt = None
     if len(dec.layers) == 0:
         de.zero_()
+    if keys is not None:
+        de = keys.scatter(de)                            # back to [B*Lk, d]: masked keys get no gradient
     # embedding side
     dcx = torch.empty(B, nc * d, dtype=torch.float32, device=g.device) if c2d else None
     ops.embed_pe_bwd(g, trg, G(dec.embed.embed.weight), dcx, nc if c2d else 0, math.sqrt(d), run.p,

@@ -379,6 +379,35 @@ class LiveRows:
         return dst
 
 
+class KeyRows(LiveRows):
+    """The compaction map of the KEY side of cross-attention, from a key-padding mask [B, Lk] (gct_key_rows): the
+    padded rows of the encoder memory are masked keys, so their K / V projections (and dK / dV) need not exist.
+    Same interface as LiveRows (gather / scatter / empty / quad_list / cstart / n_b / Mc after host())."""
+
+    def __init__(self, mask_u8, B, Lk):
+        _chk(mask_u8, "key_rows.mask", torch.uint8)
+        dev = mask_u8.device
+        M = B * Lk
+        nq = (M + 3) // 4
+        i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)            # noqa: E731
+        self.B, self.T, self.M, self.dev = B, Lk, M, dev
+        self.live = torch.empty(max(M, 1), dtype=torch.uint8, device=dev)
+        self.n_b, self.info = i32(B), i32(8)
+        self.cstart, self.quad_list = i32(B), i32(nq + 32)
+        qrank = i32(nq)
+        check(_L().gct_key_rows(_p(mask_u8), Lk, B, Lk, _p(self.live), _p(self.n_b), _p(self.info), _p(self.cstart),
+                                _p(self.quad_list), _p(qrank), _st()), "gct_key_rows")
+        self._host = None
+        self.Mc = None
+
+    def host(self):
+        if self._host is None:
+            v = self.info.tolist()
+            self._host = dict(n_live=v[0], nonprefix=v[2], padded=v[4], quads=v[5], empty=v[6])
+            self.Mc = v[4]
+        return self._host
+
+
 def linear_wgrad(dys: Sequence[torch.Tensor], lddy: int, x2d, dws: Sequence[torch.Tensor],
                  dbs: Sequence[Optional[torch.Tensor]], kt=None):
     M, K = x2d.shape
@@ -457,7 +486,7 @@ def _mb(mask, B, Lq, Lk):
 
 
 def attn_fwd(q, k, v, ld_q, ld_k, ld_v, mask, B, H, Lq, Lk, dk, p, seed, site, out=None,
-             want_probs=False):
+             want_probs=False, keys=None):
     """q/k/v: tensors whose data_ptr is element (b=0,l=0,h=0,0) with row strides ld_*.
     mask: None | MaskBits | uint8 [B,Lk] / [B,1,Lk] (key padding) / [B,Lq,Lk] (packed on the fly)."""
     dev = q.device
@@ -467,19 +496,22 @@ def attn_fwd(q, k, v, ld_q, ld_k, ld_v, mask, B, H, Lq, Lk, dk, p, seed, site, o
     mp, sb, sq = _mb(mask, B, Lq, Lk)
     check(_L().gct_attn_fwd(_p(q), ld_q, _p(k), ld_k, _p(v), ld_v, mp, sb, sq, _p(o),
                             o.stride(0), _p(lse), _p(probs), B, H, Lq, Lk, dk,
-                            1.0 / math.sqrt(dk), p, seed, site, _st()), "gct_attn_fwd")
+                            1.0 / math.sqrt(dk), p, seed, site, None if keys is None else _p(keys.cstart),
+                            None if keys is None else _p(keys.n_b), _st()), "gct_attn_fwd")
     return o, lse, probs
 
 
 def attn_bwd(q, k, v, ld_q, ld_k, ld_v, mask, o, dout, lse, dq, dk_, dv, ld_dq, ld_dk, ld_dv,
-             B, H, Lq, Lk, dk, p, seed, site, live=None, kv_compact=False):
-    """live (LiveRows): dout / dq are quad-compacted; kv_compact: so are dk / dv (self-attention)."""
+             B, H, Lq, Lk, dk, p, seed, site, live=None, kv_compact=False, keys=None):
+    """live (LiveRows): dout / dq are quad-compacted; kv_compact: so are dk / dv (self-attention); keys (KeyRows):
+    k / v / dk / dv hold the visible keys only (cross-attention)."""
     mp, sb, sq = _mb(mask, B, Lq, Lk)
     check(_L().gct_attn_bwd(_p(q), ld_q, _p(k), ld_k, _p(v), ld_v, mp, sb, sq, _p(o),
                             _p(dout), o.stride(0), _p(lse), _p(dq), ld_dq, _p(dk_), ld_dk,
                             _p(dv), ld_dv, B, H, Lq, Lk, dk, 1.0 / math.sqrt(dk), p, seed, site,
                             None if live is None else _p(live.cstart), None if live is None else _p(live.n_b),
-                            int(bool(kv_compact)), _st()), "gct_attn_bwd")
+                            int(bool(kv_compact)), None if keys is None else _p(keys.cstart),
+                            None if keys is None else _p(keys.n_b), _st()), "gct_attn_bwd")
 
 
 def _mask_strides(mask_u8, B, Lq, Lk):

@@ -201,6 +201,13 @@ int gct_live_rows(const float* g, int64_t ld, int B, int T, int cols, const uint
                   int64_t mask_sq, uint8_t* live, int32_t* n_b, int32_t* info, int32_t* cstart,
                   int32_t* quad_list, int32_t* qrank_ws, int32_t* tile_list, int32_t* tile_count,
                   uint8_t* tile_flags_ws, void* stream);
+/* The same compaction map for the KEY side of cross-attention, from a key-padding mask [B][Lk] (element (b,k) at
+ * mask[b*mask_sb + k]): padded rows of the encoder memory are masked keys -- their K / V projections are never used
+ * and their dK / dV are zero -- so the K / V GEMMs and their backward can run on the visible rows only.  Usable when
+ * info[2] == 0 (visible keys are a prefix of every row) and info[6] == 0 (every sample sees a key).
+ * info: [0] visible keys, [2] non-prefix samples, [4] compact rows, [5] live quads, [6] samples without a visible key. */
+int gct_key_rows(const uint8_t* mask, int64_t mask_sb, int B, int Lk, uint8_t* live, int32_t* n_b, int32_t* info,
+                 int32_t* cstart, int32_t* quad_list, int32_t* qrank_ws, void* stream);
 int gct_gather_quads(const float* src, int64_t ld, int64_t M, const int32_t* quad_list, int64_t nrows, int cols,
                      float* dst, int64_t ldd, void* stream);
 int gct_scatter_quads(const float* src, int64_t ld, const int32_t* quad_list, int64_t nrows, int cols, float* dst,
@@ -234,7 +241,10 @@ int gct_attn_mask_pack(const uint8_t* mask, int64_t mask_sb, int64_t mask_sq, in
 int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
                  int64_t ldv, const uint32_t* mbits, int64_t mb_sb, int64_t mb_sq,
                  float* o, int64_t ldo, float* lse, float* probs, int B, int H, int Lq, int Lk,
-                 int dk, float scale, float p, uint64_t seed, uint32_t site, void* stream);
+                 int dk, float scale, float p, uint64_t seed, uint32_t site, const int32_t* kstart,
+                 const int32_t* klen, void* stream);
+/* kstart / klen (nullable, together; gct_key_rows): k and v hold only the VISIBLE keys of every sample, quad-compacted:
+ * the rows of sample b start at kstart[b] and there are klen[b] of them (keys klen[b]..Lk-1 are masked by mbits). */
 /* dq/dk/dv written (overwrite) with the same layout as q/k/v.
  * cstart / nlive (nullable, together): dout and dq are quad-compacted (gct_live_rows): the rows of sample b start at
  * cstart[b] and only its first nlive[b] query rows exist; kv_compact != 0 (self-attention, Lq == Lk): dk / dv live
@@ -244,7 +254,9 @@ int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const
                  const float* o, const float* dout, int64_t ldo, const float* lse,
                  float* dq, int64_t lddq, float* dk_, int64_t lddk, float* dv, int64_t lddv,
                  int B, int H, int Lq, int Lk, int dk, float scale, float p, uint64_t seed,
-                 uint32_t site, const int32_t* cstart, const int32_t* nlive, int kv_compact, void* stream);
+                 uint32_t site, const int32_t* cstart, const int32_t* nlive, int kv_compact,
+                 const int32_t* kstart, const int32_t* klen, void* stream);
+/* kstart / klen as in gct_attn_fwd: k, v AND dk, dv hold the visible keys only (excludes kv_compact). */
 
 /* ------------------------------------------------- K6: reparameterisation + KL */
 /* Model/sublayers.py:14-20 / Model/cvaetf.py:63-69: z = eps*exp(0.5*log_var)+mu.

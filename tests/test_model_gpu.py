@@ -501,8 +501,9 @@ def test_zero_gradient_rows_with_arbitrary_masks_vs_oracle(case):
 @pytest.mark.parametrize("mtype,kw,B,S,p", [("pscavaetf", {}, 9, 70, 0.0), ("pvaetf", {}, 16, 77, 0.2),
                                             ("vaetf", dict(N=2, d_model=512, dff=2048, h=8, latent_dim=128), 48, 80, 0.1)])
 def test_compacted_decoder_backward_matches_dense(mtype, kw, B, S, p, monkeypatch):
-    """The decoder backward on quad-compacted live rows (engine.decoder_trunk_bwd, csrc/liverows.hip) against the
-    dense path on the same inputs, seeds and dropout masks: every parameter gradient.  The dropout cases prove that
+    """The decoder backward on quad-compacted live rows (engine.decoder_trunk_bwd, csrc/liverows.hip) and the
+    cross-attention K / V path on the visible rows of the encoder memory only (engine.decoder_trunk_fwd, ops.KeyRows)
+    against the dense paths on the same inputs, seeds and dropout masks: loss and every parameter gradient.  The dropout cases prove that
     the mask of a compact quad is regenerated from its ORIGINAL quad (GEMM epilogue, dropout backward, attention)."""
     from gct_plus_amd import engine
     ds = synthetic.make_dataset(B, S, mtype, seed=31)
@@ -511,6 +512,7 @@ def test_compacted_decoder_backward_matches_dense(mtype, kw, B, S, p, monkeypatc
     grads, took = {}, {}
     for mode in (True, False):
         monkeypatch.setattr(engine, "COMPACT_BWD", mode)
+        monkeypatch.setattr(engine, "COMPACT_KV", mode)          # cross-attention over the visible memory rows only
         seen = []
         real = engine.ops.LiveRows.gather
         monkeypatch.setattr(engine.ops.LiveRows, "gather", lambda self, *a, **k: (seen.append(1), real(self, *a, **k))[1])
@@ -522,6 +524,7 @@ def test_compacted_decoder_backward_matches_dense(mtype, kw, B, S, p, monkeypatc
         loss.backward()
         torch.cuda.synchronize()
         grads[mode] = {n: q.grad.detach().clone() for n, q in model.named_parameters() if q.grad is not None}
+        grads[mode]["__loss__"] = loss.detach().reshape(1).clone()
         took[mode] = len(seen)
         monkeypatch.setattr(engine.ops.LiveRows, "gather", real)
     assert took[True] > 0 and took[False] == 0           # the compact path really ran (and only when enabled)
