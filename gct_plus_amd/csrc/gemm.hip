@@ -67,6 +67,8 @@ struct GemmArgs {
   int64_t row_base;  // rows in front of this launch's row 0 (a launch on a row range keeps the dropout coordinates)
   const int32_t* quad_map;  // rows are a quad compaction (csrc/liverows.hip): dropout coordinates of compact quad q are
                             // those of original quad quad_map[q] (nullptr: identity)
+  int64_t pre_rows;         // > 0 (with quad_map): pre_in keeps the forward's row space (pre_rows rows) and is read
+                            // through the quad map -- no gathered copy of the 4d-wide pre-activation is needed
   const int32_t* kt_list;   // bf16x6 wgrad: ascending 32-row K-tile indices to reduce over (nullptr: all)
   const int32_t* kt_count;  // device scalar: entries of kt_list
   const uint16_t* bp0;  // bf16x6 kernels: pre-split planes of the B operand (same element offsets as b)
@@ -77,6 +79,13 @@ struct GemmArgs {
 };
 
 enum { EPI_SLAB = 32, EPI_D0 = 16 };
+
+// row of pre_in that belongs to row `row` (+0..3, row % 4 == 0) of this launch; -1: none (padding)
+__device__ __forceinline__ int64_t pre_row0(const GemmArgs& g, int64_t row) {
+  if (g.pre_rows <= 0 || !g.quad_map) return row;
+  const int v = g.quad_map[(row + g.row_base) >> 2];
+  return v < 0 ? -1 : (int64_t)v * 4;
+}
 
 // quad (row >> 2) whose Philox stream covers `row` of this launch
 __device__ __forceinline__ uint32_t drop_quad(const GemmArgs& g, int64_t row) {
@@ -401,7 +410,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
               v += cbase[off];
               break;
             case EPI_D0 + GCT_DEPI_GELU_BWD: {
-              const float u = g.pre_in[off];
+              float u = 0.f;
+              if (g.pre_rows > 0) {
+                const int64_t er0 = pre_row0(g, row_base);
+                if (er0 >= 0 && er0 + e < g.pre_rows) u = g.pre_in[(er0 + e) * g.ldc + cloc];
+              } else {
+                u = g.pre_in[off];
+              }
               v = keep ? v * gct_gelu_grad(u) * g.keep_scale : 0.f;
             } break;
             default:
@@ -461,10 +476,15 @@ struct FastEpi {
   __device__ __forceinline__ void prefetch(float4 (&x)[4], int64_t row0, const float* cbase,
                                            int64_t cloc) const {
     const float* eb = extra_base(cbase);
+    int64_t er0 = row0, elim = g.M;
+    if (g.epi == EPI_D0 + GCT_DEPI_GELU_BWD && g.pre_rows > 0) {
+      er0 = pre_row0(g, row0);
+      elim = er0 < 0 ? -1 : g.pre_rows;
+    }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       x[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + rr < g.M) x[rr] = *reinterpret_cast<const float4*>(eb + (row0 + rr) * g.ldc + cloc);
+      if (row0 + rr < g.M && er0 + rr < elim) x[rr] = *reinterpret_cast<const float4*>(eb + (er0 + rr) * g.ldc + cloc);
     }
   }
   __device__ __forceinline__ void apply(float4 (&v)[4], int64_t row0, int64_t col0,
@@ -1287,7 +1307,7 @@ static int linear_dgrad_impl(const float* dy0, const float* dy1, const float* dy
                              const float* w2, int64_t ldw, int K, float* dx, int64_t lddx,
                              int depi, const float* pre, float p, uint64_t seed, uint32_t site,
                              void* stream, const uint16_t* wp0, int64_t pstride, float* ws,
-                             const int32_t* quad_map = nullptr) {
+                             const int32_t* quad_map = nullptr, int64_t pre_rows = 0) {
   GCT_CHECK_ARG(dy0 && w0 && dx && M >= 0 && K > 0 && nseg >= 1 && nseg <= 3 && nper > 0,
                 "linear_dgrad: bad args");
   GCT_CHECK_ARG(!quad_map || M % 4 == 0, "linear_dgrad: compacted rows come in quads");
@@ -1305,6 +1325,7 @@ static int linear_dgrad_impl(const float* dy0, const float* dy1, const float* dy
   g.thr = gct_drop_threshold(p); g.keep_scale = 1.0f / (1.0f - p); g.rng = gct_rng_make(seed, site);
   g.bp0 = wp0; g.bp_stride = pstride;
   g.quad_map = quad_map;
+  g.pre_rows = quad_map ? pre_rows : 0;
   const bool vec = al16(dy0) && al16(dy1) && al16(dy2) && al16(w0) && al16(w1) && al16(w2) &&
                    (lddy % 4 == 0) && (ldw % 4 == 0) && (nper % 4 == 0) && (K % 4 == 0);
   return launch<true, false>(g, vec, (hipStream_t)stream, ws, ws ? INT64_MAX : 0);   // ws sized by gct_linear_dgrad_ws_bytes
@@ -1324,9 +1345,9 @@ extern "C" int gct_linear_dgrad_p(const float* dy0, const float* dy1, const floa
                                   const float* w2, int64_t ldw, const uint16_t* wp0,
                                   int64_t plane_stride, int K, float* dx, int64_t lddx, int depi,
                                   const float* pre, float p, uint64_t seed, uint32_t site,
-                                  float* ws, const int32_t* quad_map, void* stream) {
+                                  float* ws, const int32_t* quad_map, int64_t pre_rows, void* stream) {
   return linear_dgrad_impl(dy0, dy1, dy2, lddy, M, nseg, nper, w0, w1, w2, ldw, K, dx, lddx, depi, pre,
-                           p, seed, site, stream, wp0, plane_stride, ws, quad_map);
+                           p, seed, site, stream, wp0, plane_stride, ws, quad_map, pre_rows);
 }
 
 static int linear_wgrad_impl(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,

@@ -212,12 +212,13 @@ def ffn_bwd(run: Run, ff, saved, dy, G: GradSink, dx_out, depi, live=None):
     kt = run.kt
     if live is not None:          # quad-compacted rows: gather what the forward saved
         M, kt = live.Mc, None
-        x, pre, hdn = live.gather(x), live.gather(pre), live.gather(hdn)
+        x, hdn = live.gather(x), live.gather(hdn)     # (pre stays in place: the GELU-backward epilogue reads it
+                                                      #  through the quad map)
     g = ops.dropout_bwd(dy, run.p, run.seed, site_o, live=live) if (fused and run.p > 0) else dy
     ops.linear_wgrad([g], d, hdn, [G(ff.linear_2.weight)], [G(ff.linear_2.bias)], kt=kt)
     dpre = _empty(M, dff, dy) if live is None else live.empty(dff)
     ops.linear_dgrad([g], d, M, [ff.linear_2.weight], dpre, depi=ops.DEPI_GELU_BWD, pre=pre,
-                     p=run.p, seed=run.seed, site=site_h, live=live)
+                     p=run.p, seed=run.seed, site=site_h, live=live, pre_full=live is not None)
     ops.linear_wgrad([dpre], dff, x, [G(ff.linear_1.weight)], [G(ff.linear_1.bias)], kt=kt)
     ops.linear_dgrad([dpre], dff, M, [ff.linear_1.weight], dx_out, depi=depi)
 

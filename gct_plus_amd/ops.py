@@ -285,7 +285,7 @@ def linear_fwd(x2d, ws_: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Ten
 
 
 def linear_dgrad(dys: Sequence[torch.Tensor], lddy: int, M: int, ws_: Sequence[torch.Tensor], dx,
-                 depi=DEPI_STORE, pre=None, p=0.0, seed=0, site=0, live=None):
+                 depi=DEPI_STORE, pre=None, p=0.0, seed=0, site=0, live=None, pre_full=False):
     nper, K = ws_[0].shape
     d = _seg3(dys)
     w = _seg3(ws_)
@@ -297,7 +297,9 @@ def linear_dgrad(dys: Sequence[torch.Tensor], lddy: int, M: int, ws_: Sequence[t
         check(_L().gct_linear_dgrad_p(d[0], d[1], d[2], lddy, M, len(ws_), nper, w[0], w[1], w[2],
                                       ws_[0].stride(0), wp, pstride, K, _p(dx), dx.stride(0), depi,
                                       _p(pre), p, seed, site, _p(wsb),
-                                      None if live is None else _p(live.quad_list), _st()), "gct_linear_dgrad_p")
+                                      None if live is None else _p(live.quad_list),
+                                      pre.shape[0] if (live is not None and pre is not None and pre_full) else 0,
+                                      _st()), "gct_linear_dgrad_p")
 
 
 def nonzero_row_tiles(x2d: torch.Tensor):

@@ -166,9 +166,10 @@ int gct_linear_dgrad_p(const float* dy0, const float* dy1, const float* dy2, int
                        const float* w0, const float* w1, const float* w2, int64_t ldw,
                        const uint16_t* wp0, int64_t plane_stride, int K,
                        float* dx, int64_t lddx, int depi, const float* pre, float p, uint64_t seed,
-                       uint32_t site, float* ws, const int32_t* quad_map, void* stream);
+                       uint32_t site, float* ws, const int32_t* quad_map, int64_t pre_rows, void* stream);
 /* quad_map (nullable): the M rows are quad-compacted (gct_live_rows); GCT_DEPI_GELU_BWD then regenerates the dropout
- * mask of compact quad q from original quad quad_map[q] (pre is compact like dy / dx). */
+ * mask of compact quad q from original quad quad_map[q].  pre_rows == 0: pre is compact like dy / dx; pre_rows > 0:
+ * pre keeps the forward's row space (pre_rows rows) and is read through the quad map (no gathered copy needed). */
 /* ws of gct_linear_dgrad_p (nullable): >= gct_linear_dgrad_ws_bytes(M, nseg*nper, K).  With a workspace the
  * bf16x6 forward / dgrad launches balance a partial last round of tiles (K-split tail launch + fix-up kernel);
  * gct_linear_fwd_ws_bytes covers the forward (skinny split-K or tail slabs, whichever the launch would use). */
