@@ -462,7 +462,9 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
   uint8_t* rowlive = rowok + LQP;                                 // [LQP] dO row has a non-zero element
   StageOff<DK, NT> kvo;                  // ldk == ldv (checked on the host)
   kvo.init(a.ldk, a.Lk, tid);
+  ASTAMP_DECL;
   for (int pair = blockIdx.x; pair < a.npairs; pair += (int)gridDim.x) {
+    ASTAMP(0);                           // loop seam
     const int b = pair / a.H, h = pair - b * a.H;
     const int64_t lrow0 = ((int64_t)b * a.H + h) * a.Lq;
     const int Lq_e = a.nlive ? a.nlive[b] : a.Lq;                               // query rows that exist in dout / dq
@@ -501,7 +503,9 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
       sk.store(R0, Lk_in, LKP, tid);
       sv.store(R1, Lk_in, LKP, tid);
     }
+    ASTAMP(1);                           // loads issued, mask rows, wait for K / V, LDS stores
     __syncthreads();
+    ASTAMP(2);                           // barrier 1
     float4 bk[NDT], bv[NDT];
     bool tile_live = false;
     for (int u = wave; u < nqt; u += NW) {
@@ -610,6 +614,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
               make_float4(qacc[dt][0] * a.scale, qacc[dt][1] * a.scale, qacc[dt][2] * a.scale, qacc[dt][3] * a.scale);
       }
     }
+    ASTAMP(3);                           // phase A
     constexpr bool FRAG_STAGE = NT <= NW;   // one query tile and one key tile per wave: stage through registers
     if (FRAG_STAGE) {
       // this wave's key tile of phase B: K / V rows are still in LDS
@@ -617,6 +622,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
       row_frag<NDT>(bv, R1, 16 * wave + c16, g);
     }
     __syncthreads();      // K, V no longer needed; del_s / lse_s / rowlive / keep bits complete
+    ASTAMP(4);                           // own K / V rows from LDS + barrier 2
     // ---------------------------------------------------------------- phase B: Q, dO in LDS -> dK, dV
     if (FRAG_STAGE) {
       // Q and dO cross HBM once: every wave still holds the rows of its query tile as fragments, in exactly the
@@ -642,7 +648,9 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
       sq.store(R0, Lq_e, LQP, tid);
       sd.store(R1, Lq_e, LQP, tid);
     }
+    ASTAMP(5);                           // Q / dO fragments -> LDS
     __syncthreads();
+    ASTAMP(6);                           // barrier 3
     for (int t = wave; t < nkt; t += NW) {
       const int k = 16 * t + c16;
       if (16 * t >= Lk_e) continue;        // compact self-attention: dead keys have no row (and no gradient)
@@ -713,8 +721,10 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
         }
       }
     }
+    ASTAMP(7);                           // phase B
     __syncthreads();      // before the next pair's staging overwrites the region
   }
+  ASTAMP_OUT;
 }
 
 // one thread per packed word: bits[b][q][w] = OR_j (mask[b,q,32w+j] != 0) << j

@@ -44,5 +44,40 @@ int main() {
       }
     }
   }
+  // ---- backward (dropout 0.1, ragged key-padding mask): same stamps, 8 segments
+  {
+    float *dout, *dqkv;
+    hipMalloc(&dout, (size_t)B * L * d * 4); hipMalloc(&dqkv, (size_t)B * L * 3 * d * 4);
+    hipMemcpy(dout, h.data(), (size_t)B * L * d * 4, hipMemcpyHostToDevice);
+    std::vector<uint8_t> m(B * L);
+    for (int b = 0; b < B; ++b) for (int j = 0; j < L; ++j) m[b * L + j] = (j < 20 + (b * 7) % 40);
+    hipMemcpy(mask, m.data(), m.size(), hipMemcpyHostToDevice);
+    gct_attn_mask_pack(mask, L, 0, B, L, L, bits, nullptr);
+    AttnArgs a = {};
+    a.q = qkv; a.k = qkv + d; a.v = qkv + 2 * d; a.ldq = a.ldk = a.ldv = 3 * d;
+    a.mbits = bits; a.mb_sb = 8; a.mb_sq = 0; a.o_in = o; a.dout = dout; a.ldo = d; a.lse_in = lse;
+    a.dq = dqkv; a.dk = dqkv + d; a.dv = dqkv + 2 * d; a.lddq = a.lddk = a.lddv = 3 * d;
+    a.B = B; a.H = H; a.Lq = L; a.Lk = L; a.npairs = B * H; a.scale = 0.125f;
+    a.thr = gct_drop_threshold(0.1f); a.keep_scale = 1.f / 0.9f; a.rng = gct_rng_make(1, 1);
+    a.stamps = st;
+    const size_t lds = (size_t)(160) * 68 * 4 + 80 * 8 + 80 * 3 * 8 + 160;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipMemset(st, 0, 64 * 6 * 8 * 8);
+      hipLaunchKernelGGL((attn_bwd_kernel<4, 6>), dim3(1024), dim3(ATT_THREADS), lds, 0, a);
+      hipDeviceSynchronize();
+    }
+    std::vector<unsigned long long> hs(64 * 6 * 8);
+    hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
+    const char* nm[8] = {"seam", "loads+mask+lds store", "barrier1", "phase A", "own K/V + barrier2", "frag->lds", "barrier3", "phase B"};
+    printf("backward, dropout 0.1, ragged (ticks per wave over 4 pairs)\n");
+    for (int w = 0; w < 6; ++w) {
+      double seg[8] = {0};
+      for (int b = 0; b < 64; ++b) for (int i = 0; i < 8; ++i) seg[i] += (double)hs[(b * 6 + w) * 8 + i] / 64;
+      double tot = 0; for (int i = 0; i < 8; ++i) tot += seg[i];
+      printf(" wave %d total %.0f:", w, tot);
+      for (int i = 0; i < 8; ++i) printf("  %s %.0f", nm[i], seg[i]);
+      printf("\n");
+    }
+  }
   return 0;
 }
