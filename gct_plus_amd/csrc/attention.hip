@@ -442,6 +442,157 @@ __global__ __launch_bounds__(ATT_THREADS, OCC) void attn_fwd_kernel(const AttnAr
   ASTAMP_OUT;
 }
 
+// ------------------------------------------------------------------------------ forward, direct
+// One WAVE per (pair, query tile), no LDS, no barrier: the K and V fragments of the key tiles the query tile can see
+// come straight from L2 (a pair's K, V are 2 x L x 256 B and are read by its 5-6 query tiles within microseconds of each
+// other), so a wave never waits for another wave and the hardware dispatcher balances the SIMDs -- the LDS kernel
+// above puts 5-6 query tiles on the 4 SIMDs of a CU the same way for every pair and ends every pair on a barrier.
+// Same arithmetic, same order of operations, same dropout bits as fwd_unit; used for L_k <= 96.
+template <int NDT> struct VecN;
+template <> struct VecN<4> { typedef float4 T; };
+template <> struct VecN<2> { typedef float2 T; };
+template <> struct VecN<1> { typedef float T; };
+template <int NDT> __device__ __forceinline__ float vec_at(const typename VecN<NDT>::T& v, int i);
+template <> __device__ __forceinline__ float vec_at<4>(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+template <> __device__ __forceinline__ float vec_at<2>(const float2& v, int i) { return i == 0 ? v.x : v.y; }
+template <> __device__ __forceinline__ float vec_at<1>(const float& v, int) { return v; }
+
+template <int NDT, int NT>
+__global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs a) {
+  constexpr int DK = 16 * NDT, MW = (NT + 1) / 2;
+  typedef typename VecN<NDT>::T VT;
+  const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+  const int nqt = (a.Lq + 15) >> 4, nkt = (a.Lk + 15) >> 4;
+  const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+  if (item >= a.npairs * nqt) return;
+  const int pair = item / nqt, u = item - pair * nqt;
+  const int b = pair / a.H, h = pair - b * a.H;
+  const int q = 16 * u + c16;
+  const int Lk_in = a.klen ? a.klen[b] : a.Lk;            // keys that exist as rows; the others are masked keys
+  const int64_t kr0 = a.kstart ? (int64_t)a.kstart[b] : (int64_t)b * a.Lk;
+  const int klast = Lk_in > 0 ? Lk_in - 1 : 0;
+  float4 bq[NDT];
+  row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, q, g);
+  uint4 mraw[(MW + 3) / 4] = {};
+  if (a.mbits) mask_row_raw<MW>(mraw, a, b, q);
+  uint32_t mw[MW];
+  mask_row_use<MW>(mw, mraw, a, q);
+  const uint32_t use = tiles_for_q<MW>(mw, q, a.Lq, a.Lk, nkt);
+  uint32_t rowvis = 0;
+#pragma unroll
+  for (int w = 0; w < MW; ++w) rowvis |= mw[w] & range_word(w, a.Lk);
+  // K fragments of the visible tiles (rows beyond the existing keys re-read the last one: their scores are masked)
+  const char* kbase = reinterpret_cast<const char*>(a.k + kr0 * a.ldk + h * DK);                  // wave-uniform
+  float4 ak[NT][NDT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if ((use >> t) & 1u) {
+      const int rr = 16 * t + c16 < klast ? 16 * t + c16 : klast;
+      const uint32_t off = (uint32_t)((rr * a.ldk + g * 4 * NDT) * 4);
+#pragma unroll
+      for (int j = 0; j < NDT; ++j) ak[t][j] = *reinterpret_cast<const float4*>(kbase + off + 16 * j);
+    }
+  f32x4 sacc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if ((use >> t) & 1u) sacc[t] = dot_frag<NDT>(ak[t], bq, sacc[t]);
+  // V fragments, requested now and consumed after the softmax: lane (c16, g) holds V[16t + 4g + r][NDT c16 .. + NDT)
+  // -- output tile dt of the P.V product covers the head columns {NDT m + dt}
+  const char* vbase = reinterpret_cast<const char*>(a.v + kr0 * a.ldv + h * DK);                  // wave-uniform
+  VT av[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if ((use >> t) & 1u) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kk = 16 * t + 4 * g + r;
+        const int rr = kk < klast ? kk : klast;
+        av[t][r] = *reinterpret_cast<const VT*>(vbase + (uint32_t)((rr * a.ldv + NDT * c16) * 4));
+      }
+    }
+  // scale + mask + softmax (as fwd_unit)
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if ((use >> t) & 1u) {
+      const uint32_t nib = mw[t >> 1] >> ((t & 1) * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sv = score_of(sacc[t][r] * a.scale, 16 * t + 4 * g + r < a.Lk, (nib >> r) & 1u);
+        sacc[t][r] = sv;
+        m = fmaxf(m, sv);
+      }
+    }
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  if (m == -INFINITY) m = 0.f;
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if ((use >> t) & 1u) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(sacc[t][r] - m);
+        sacc[t][r] = e;
+        l += e;
+      }
+    }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  const int64_t grow = ((int64_t)b * a.H + h) * a.Lq + q;
+  if (g == 0 && q < a.Lq) (a.lse + ((int64_t)b * a.H + h) * a.Lq)[q] = (rowvis ? m : 0.f) + __logf(l);
+  uint64_t keep = keep_bits_row<NT>(a, (uint32_t)grow, use, g);
+  if (a.klen) {                        // keys without a row: V is zero there (only a row that sees no key weighs them)
+    uint64_t exist = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = Lk_in - 16 * t - 4 * g;
+      exist |= (uint64_t)(n >= 4 ? 0xfu : (n > 0 ? ((1u << n) - 1u) : 0u)) << (4 * t);
+    }
+    keep &= exist;
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if (t < nkt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = sacc[t][r] * inv;
+        const int k = 16 * t + 4 * g + r;
+        if (a.probs && q < a.Lq && k < a.Lk) a.probs[grow * a.Lk + k] = p;
+        sacc[t][r] = ((keep >> (4 * t + r)) & 1ull) ? p * a.keep_scale : 0.f;
+      }
+    }
+  // O^T[m][q] (tile dt) = sum_k V[k][NDT m + dt] * Pdrop^T[k][q]
+  f32x4 oacc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if ((use >> t) & 1u) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) oacc[dt] = mfma16(vec_at<NDT>(av[t][r], dt), sacc[t][r], oacc[dt]);
+      }
+    }
+  if (q < a.Lq) {
+    char* obase = reinterpret_cast<char*>(a.o + (int64_t)b * a.Lq * a.ldo + h * DK);             // wave-uniform
+    const uint32_t ooff = (uint32_t)((q * a.ldo + 4 * NDT * g) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {      // accumulator row i of group g is head column NDT (4g + i) + dt
+      if constexpr (NDT == 4)
+        *reinterpret_cast<float4*>(obase + ooff + 16 * i) = make_float4(oacc[0][i], oacc[1][i], oacc[2][i], oacc[3][i]);
+      else if constexpr (NDT == 2)
+        *reinterpret_cast<float2*>(obase + ooff + 8 * i) = make_float2(oacc[0][i], oacc[1][i]);
+      else
+        *reinterpret_cast<float*>(obase + ooff + 4 * i) = oacc[0][i];
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------- backward
 template <int NDT, int NT>
 __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kernel(const AttnArgs a) {
@@ -790,6 +941,14 @@ int check_common(const char* who, const float* q, int64_t ldq, const float* k, i
 
 template <int NDT, int NT>
 int launch_fwd(const AttnArgs& a, size_t lds, hipStream_t st) {
+  static const bool lds_kernel = getenv("GCT_ATTN_FWD_LDS") != nullptr;     // A/B switch for benchmarks
+  if constexpr (NT <= 6) {
+    if (!lds_kernel) {
+      const int64_t items = (int64_t)a.npairs * ((a.Lq + 15) / 16);
+      hipLaunchKernelGGL((attn_fwd_direct_kernel<NDT, NT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
+      return GCT_OK;
+    }
+  }
   // persistent workgroups: as many as are resident together (2 per CU: 6 waves at <= 168 VGPRs)
   const int per_cu = NT > 8 ? 1 : 2;
   const int64_t want = (int64_t)num_cus() * per_cu;

@@ -1103,6 +1103,8 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
     if (skinny_ws && gct_aligned16(skinny_ws)) {      // split-K: >= 4 K-tiles per split, ~768 blocks
       ns = 768 / st_;
       if (ns > nkt / 4) ns = nkt / 4;
+      static const int ns_cap = getenv("GCT_SKINNY_SPLIT_MAX") ? atoi(getenv("GCT_SKINNY_SPLIT_MAX")) : 1 << 30;
+      if (ns > ns_cap) ns = ns_cap;
       if (ns < 1) ns = 1;
     }
     if (ns <= 1) {
