@@ -65,6 +65,12 @@ struct AttnArgs {
   // sample b start at kstart[b] and only its first klen[b] keys exist (the rest are masked keys: zero rows in LDS);
   // the backward's dk / dv live in the same rows
   const int32_t *kstart, *klen;
+  // direct backward (two launches): per query row {lse, delta, masked score, dO row non-zero}, the dropout keep
+  // bits in the packed-mask layout, one word of visited key tiles per (pair, query tile) -- written by the dQ kernel, read by
+  // the dK / dV kernel
+  float4* ws_meta;
+  uint32_t* ws_keep;
+  uint32_t* ws_use;                    // per (pair, query tile): the key tiles it computed (0: dead tile)
   int B, H, Lq, Lk, npairs;
   float scale, keep_scale;
   uint32_t thr;
@@ -448,14 +454,51 @@ __global__ __launch_bounds__(ATT_THREADS, OCC) void attn_fwd_kernel(const AttnAr
 // other), so a wave never waits for another wave and the hardware dispatcher balances the SIMDs -- the LDS kernel
 // above puts 5-6 query tiles on the 4 SIMDs of a CU the same way for every pair and ends every pair on a barrier.
 // Same arithmetic, same order of operations, same dropout bits as fwd_unit; used for L_k <= 96.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// NDT consecutive floats as a NATIVE vector (HIP's float4 is a struct: its copies are memcpy calls that keep whole
+// operand arrays in scratch memory when they sit under a condition)
 template <int NDT> struct VecN;
-template <> struct VecN<4> { typedef float4 T; };
-template <> struct VecN<2> { typedef float2 T; };
+template <> struct VecN<4> { typedef f32x4 T; };
+template <> struct VecN<2> { typedef f32x2 T; };
 template <> struct VecN<1> { typedef float T; };
 template <int NDT> __device__ __forceinline__ float vec_at(const typename VecN<NDT>::T& v, int i);
-template <> __device__ __forceinline__ float vec_at<4>(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
-template <> __device__ __forceinline__ float vec_at<2>(const float2& v, int i) { return i == 0 ? v.x : v.y; }
+template <> __device__ __forceinline__ float vec_at<4>(const f32x4& v, int i) { return v[i]; }
+template <> __device__ __forceinline__ float vec_at<2>(const f32x2& v, int i) { return v[i]; }
 template <> __device__ __forceinline__ float vec_at<1>(const float& v, int) { return v; }
+
+// A wave-private LDS tile [16][DK + 4].  Rows arrive from global memory COALESCED -- lane (c16, g), r = 0..3 holds row
+// 4g + r, head columns NDT c16 .. (16 lanes cover one row's 64 NDT bytes) -- and leave as the row-per-lane fragments
+// the products over the head dimension need.  A row-per-lane float4 load straight from global memory costs the texture
+// addresser about one lane per cycle (PMC: 57 cycles of TA_BUSY per load instruction against 16 for a coalesced one,
+// TA 57-65 % busy in the first version of these kernels).  One wave's LDS instructions execute in order, so put -> get
+// needs no barrier; the compiler is told to keep the order.
+template <int NDT>
+struct WaveTile {
+  static constexpr int SD = 16 * NDT + 4;
+  typedef typename VecN<NDT>::T VT;
+  float* t;
+  __device__ __forceinline__ void put(const VT (&v)[4], int g, int c16) const {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<VT*>(t + (4 * g + r) * SD + NDT * c16) = v[r];
+  }
+  __device__ __forceinline__ void get(float4 (&f)[NDT], int g, int c16) const {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < NDT; ++j) f[j] = *reinterpret_cast<const float4*>(t + c16 * SD + g * 4 * NDT + 4 * j);
+    __builtin_amdgcn_wave_barrier();
+  }
+};
+// the coalesced load: rows row0 + min(4g + r, last) of a [rows][ld] head slice whose (row 0, column 0) is `base`
+template <int NDT>
+__device__ __forceinline__ void tile_load(typename VecN<NDT>::T (&v)[4], const char* base, int ld, int row0, int last,
+                                          int g, int c16) {
+  typedef typename VecN<NDT>::T VT;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rr = row0 + 4 * g + r;
+    v[r] = *reinterpret_cast<const VT*>(base + (uint32_t)(((rr < last ? rr : last) * ld + NDT * c16) * 4));
+  }
+}
 
 template <int NDT, int NT>
 __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs a) {
@@ -471,8 +514,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs 
   const int Lk_in = a.klen ? a.klen[b] : a.Lk;            // keys that exist as rows; the others are masked keys
   const int64_t kr0 = a.kstart ? (int64_t)a.kstart[b] : (int64_t)b * a.Lk;
   const int klast = Lk_in > 0 ? Lk_in - 1 : 0;
-  float4 bq[NDT];
-  row_frag_global<NDT>(bq, a.q, a.ldq, b, h, a.Lq, q, g);
+  __shared__ __attribute__((aligned(16))) float tiles[4][2][16 * WaveTile<NDT>::SD];
+  const int wv = threadIdx.x >> 6;
+  const WaveTile<NDT> T0{tiles[wv][0]}, T1{tiles[wv][1]};
+  // Q rows of this tile and the K rows of the visible key tiles arrive coalesced and become row-per-lane fragments in
+  // the wave's LDS tiles (WaveTile); rows beyond the existing keys re-read the last one: their scores are masked
+  VT tq[4];
+  tile_load<NDT>(tq, reinterpret_cast<const char*>(a.q + (int64_t)b * a.Lq * a.ldq + h * DK), a.ldq, 16 * u, a.Lq - 1, g, c16);
   uint4 mraw[(MW + 3) / 4] = {};
   if (a.mbits) mask_row_raw<MW>(mraw, a, b, q);
   uint32_t mw[MW];
@@ -481,23 +529,30 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs 
   uint32_t rowvis = 0;
 #pragma unroll
   for (int w = 0; w < MW; ++w) rowvis |= mw[w] & range_word(w, a.Lk);
-  // K fragments of the visible tiles (rows beyond the existing keys re-read the last one: their scores are masked)
   const char* kbase = reinterpret_cast<const char*>(a.k + kr0 * a.ldk + h * DK);                  // wave-uniform
-  float4 ak[NT][NDT];
+  VT tk[NT][4];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
-    if ((use >> t) & 1u) {
-      const int rr = 16 * t + c16 < klast ? 16 * t + c16 : klast;
-      const uint32_t off = (uint32_t)((rr * a.ldk + g * 4 * NDT) * 4);
-#pragma unroll
-      for (int j = 0; j < NDT; ++j) ak[t][j] = *reinterpret_cast<const float4*>(kbase + off + 16 * j);
-    }
+    if ((use >> t) & 1u) tile_load<NDT>(tk[t], kbase, a.ldk, 16 * t, klast, g, c16);
+  float4 bq[NDT];
+  T1.put(tq, g, c16);
+  T1.get(bq, g, c16);
   f32x4 sacc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < NT; ++t)
-    if ((use >> t) & 1u) sacc[t] = dot_frag<NDT>(ak[t], bq, sacc[t]);
+    if ((use >> t) & 1u) {
+      float4 ak[NDT];
+      if (t & 1) {                     // alternate: tile t+1 is written while tile t is read
+        T1.put(tk[t], g, c16);
+        T1.get(ak, g, c16);
+      } else {
+        T0.put(tk[t], g, c16);
+        T0.get(ak, g, c16);
+      }
+      sacc[t] = dot_frag<NDT>(ak, bq, sacc[t]);
+    }
   // V fragments, requested now and consumed after the softmax: lane (c16, g) holds V[16t + 4g + r][NDT c16 .. + NDT)
   // -- output tile dt of the P.V product covers the head columns {NDT m + dt}
   const char* vbase = reinterpret_cast<const char*>(a.v + kr0 * a.ldv + h * DK);                  // wave-uniform
@@ -878,6 +933,319 @@ __global__ __launch_bounds__(ATT_THREADS, (NT <= 8 ? 3 : 2)) void attn_bwd_kerne
   ASTAMP_OUT;
 }
 
+// ------------------------------------------------------------------------------ backward, direct
+// The same decomposition as the forward: no LDS, no barriers, one wave per item, operands from L2.
+//   launch 1, one wave per (pair, query tile):  S^T, dP^T -> dS^T -> dQ;  leaves {lse, delta, masked score, live} per
+//             query row, the keep bits and a live byte per tile in the workspace
+//   launch 2, one wave per (pair, key tile):    S, dP -> P_drop, dS -> dV, dK over the live query tiles
+// Arithmetic, skip predicates and dropout bits are those of attn_bwd_kernel's two phases.
+template <int NDT>
+struct DqBuf {                         // one key tile's operands of the dQ kernel, as they arrive (coalesced):
+  typename VecN<NDT>::T kt[4], vt[4];  // K / V rows 16t + 4g + r, head columns NDT c16 ..; kt is the A operand of dQ^T
+};
+
+template <int NDT, int NT>
+__global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const AttnArgs a) {
+  constexpr int DK = 16 * NDT, MW = (NT + 1) / 2;
+  const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+  const int nqt = (a.Lq + 15) >> 4, nkt = (a.Lk + 15) >> 4, LQP = 16 * nqt;
+  const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+  if (item >= a.npairs * nqt) return;
+  const int pair = item / nqt, u = item - pair * nqt;
+  const int b = pair / a.H, h = pair - b * a.H;
+  const int64_t lrow0 = (int64_t)pair * a.Lq;
+  const int Lq_e = a.nlive ? a.nlive[b] : a.Lq;                               // query rows that exist in dout / dq
+  const int64_t drow0 = a.cstart ? (int64_t)a.cstart[b] : (int64_t)b * a.Lq;  // row of (b, 0) in dout / dq
+  const int64_t kin0 = a.kstart ? (int64_t)a.kstart[b] : (int64_t)b * a.Lk;   // row of key 0 in k / v
+  const int Lk_in = a.klen ? a.klen[b] : a.Lk;                                // keys that exist as rows of k / v
+  const int klast = Lk_in > 0 ? Lk_in - 1 : 0;
+  uint32_t* visit = a.ws_use + (int64_t)pair * nqt + u;    // key tiles this query tile contributes to (launch 2)
+  if (16 * u >= Lq_e) {                       // compacted away: no dout / dq rows
+    if (lane == 0) *visit = 0;
+    return;
+  }
+  const int q = 16 * u + c16;
+  const bool real = q < Lq_e;
+  __shared__ __attribute__((aligned(16))) float tiles[4][2][16 * WaveTile<NDT>::SD];
+  const int wv = threadIdx.x >> 6;
+  const WaveTile<NDT> T0{tiles[wv][0]}, T1{tiles[wv][1]};
+  DqBuf<NDT> b0;
+  float4 bq[NDT], bd[NDT];
+  float del = 0.f;
+  int nz = 0;
+  float lse0;
+  uint4 mraw[(MW + 3) / 4] = {};
+  {
+    // this tile's Q, dO and O rows: coalesced -> the wave's LDS tiles -> row-per-lane fragments
+    float4 bo[NDT];
+    const char* qb = reinterpret_cast<const char*>(a.q + (int64_t)b * a.Lq * a.ldq + h * DK);
+    const char* db = reinterpret_cast<const char*>(a.dout + drow0 * a.ldo + h * DK);
+    const char* ob = reinterpret_cast<const char*>(a.o_in + (int64_t)b * a.Lq * a.ldo + h * DK);
+    tile_load<NDT>(b0.kt, qb, a.ldq, 16 * u, a.Lq - 1, g, c16);
+    tile_load<NDT>(b0.vt, db, a.ldo, 16 * u, Lq_e - 1, g, c16);
+    lse0 = a.lse_in[lrow0 + (q < a.Lq ? q : a.Lq - 1)];
+    if (a.mbits) mask_row_raw<MW>(mraw, a, b, q);
+    T0.put(b0.kt, g, c16);
+    T1.put(b0.vt, g, c16);
+    tile_load<NDT>(b0.kt, ob, a.ldo, 16 * u, a.Lq - 1, g, c16);
+    T0.get(bq, g, c16);
+    T1.get(bd, g, c16);
+    T0.put(b0.kt, g, c16);
+    T0.get(bo, g, c16);
+#pragma unroll
+    for (int j = 0; j < NDT; ++j) {
+      del += (bo[j].x * bd[j].x + bo[j].y * bd[j].y) + (bo[j].z * bd[j].z + bo[j].w * bd[j].w);
+      nz |= (bd[j].x != 0.f) | (bd[j].y != 0.f) | (bd[j].z != 0.f) | (bd[j].w != 0.f);
+    }
+  }
+  del += __shfl_xor(del, 16, 64);
+  del += __shfl_xor(del, 32, 64);
+  nz |= __shfl_xor(nz, 16, 64);
+  nz |= __shfl_xor(nz, 32, 64);
+  del = real ? del : 0.f;              // rows beyond Lq_e hold a copy of the last row: neutralise
+  nz = real ? nz : 0;
+  const float lse = real ? lse0 : 0.f;
+  uint32_t mw[MW];
+  mask_row_use<MW>(mw, mraw, a, q);
+  uint32_t rowvis = 0;
+#pragma unroll
+  for (int w = 0; w < MW; ++w) rowvis |= mw[w] & range_word(w, a.Lk);
+  const float masked = rowvis ? -1e9f : 0.f;          // see the forward's lse note
+  if (g == 0) a.ws_meta[(int64_t)pair * LQP + q] = make_float4(lse, del, masked, nz ? 1.f : 0.f);
+  const bool tile_live = __any(nz);
+  char* dbase = reinterpret_cast<char*>(a.dq + drow0 * a.lddq + h * DK);                          // wave-uniform
+  const uint32_t doff = (uint32_t)((q * a.lddq + 4 * NDT * g) * 4);
+  if (!tile_live) {                    // all 16 gradient rows are zero: dQ rows = 0, nothing else
+    if (lane == 0) *visit = 0;
+    if (real) {
+#pragma unroll
+      for (int i = 0; i < NDT; ++i) *reinterpret_cast<float4*>(dbase + doff + 16 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
+  const uint32_t use = tiles_for_q<MW>(mw, q, a.Lq, a.Lk, nkt);
+  if (lane == 0) *visit = use;
+  const uint64_t keepw = keep_bits_row<NT>(a, (uint32_t)(lrow0 + q), use, g);
+  uint16_t* kp_h = reinterpret_cast<uint16_t*>(a.ws_keep + ((int64_t)pair * LQP + q) * MW);
+  const char* kbase = reinterpret_cast<const char*>(a.k + kin0 * a.ldk + h * DK);                 // wave-uniform
+  const char* vbase = reinterpret_cast<const char*>(a.v + kin0 * a.ldv + h * DK);
+  // the tile loop is ROLLED over the visible tiles and dS^T of a tile goes straight into the dQ product, so nothing is
+  // kept per tile: 118 VGPRs, four waves per SIMD.  (A two-deep register prefetch of the next tile's operands measured
+  // no faster at three waves per SIMD: what hides the load latency here is the other waves.)
+  auto load = [&](DqBuf<NDT>& B_, int t) {
+    tile_load<NDT>(B_.kt, kbase, a.ldk, 16 * t, klast, g, c16);
+    tile_load<NDT>(B_.vt, vbase, a.ldv, 16 * t, klast, g, c16);
+  };
+  f32x4 qacc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) qacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](const DqBuf<NDT>& B_, int t) {
+    f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f}, pacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      float4 ak[NDT], av[NDT];                   // K / V rows 16t + c16 as row-per-lane fragments
+      T0.put(B_.kt, g, c16);
+      T1.put(B_.vt, g, c16);
+      T0.get(ak, g, c16);
+      T1.get(av, g, c16);
+      sacc = dot_frag<NDT>(ak, bq, sacc);        // S^T (unscaled)
+      pacc = dot_frag<NDT>(av, bd, pacc);        // dP^T
+    }
+    uint32_t word = mw[0];
+#pragma unroll
+    for (int w = 1; w < MW; ++w) word = (t >> 1) == w ? mw[w] : word;
+    const uint32_t nib = word >> ((t & 1) * 16 + 4 * g);
+    const uint32_t keep = (uint32_t)(keepw >> (4 * t)) & 0xfu;
+    if (a.thr) {                       // keep bits of (query row, 16 keys) for launch 2: one 16-bit store per row
+      uint32_t hw = keep << (4 * g);
+      hw |= __shfl_xor(hw, 16, 64);
+      hw |= __shfl_xor(hw, 32, 64);
+      if (g == 0) kp_h[t] = (uint16_t)hw;
+    }
+    float ds[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool inr = 16 * t + 4 * g + r < a.Lk, vis = (nib >> r) & 1u;
+      const float p = inr ? __expf(score_of(sacc[r] * a.scale, true, vis, masked) - lse) : 0.f;
+      const float dpd = ((keep >> r) & 1u) ? pacc[r] * a.keep_scale : 0.f;
+      ds[r] = (inr && vis) ? p * (dpd - del) : 0.f;            // dS^T (masked_fill passes no grad)
+    }
+    // dQ^T[m][q] (tile dt) += sum_k K[k][NDT m + dt] dS^T[k][q]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) qacc[dt] = mfma16(vec_at<NDT>(B_.kt[r], dt), ds[r], qacc[dt]);
+    }
+  };
+  for (uint32_t rem = use; rem; rem &= rem - 1) {       // wave-uniform
+    const int t0 = __builtin_ctz(rem);
+    load(b0, t0);
+    compute(b0, t0);
+  }
+  if (real) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {      // accumulator row i of group g is head column NDT (4g + i) + dt
+      if constexpr (NDT == 4)
+        *reinterpret_cast<float4*>(dbase + doff + 16 * i) =
+            make_float4(qacc[0][i] * a.scale, qacc[1][i] * a.scale, qacc[2][i] * a.scale, qacc[3][i] * a.scale);
+      else if constexpr (NDT == 2)
+        *reinterpret_cast<float2*>(dbase + doff + 8 * i) = make_float2(qacc[0][i] * a.scale, qacc[1][i] * a.scale);
+      else
+        *reinterpret_cast<float*>(dbase + doff + 4 * i) = qacc[0][i] * a.scale;
+    }
+  }
+}
+
+template <int NDT>
+struct DkvBuf {                        // one query tile's operands of the dK / dV kernel
+  typename VecN<NDT>::T tq[4], td[4];  // Q / dO rows 16u + 4g + r, head columns NDT c16 ..: A operands of dK^T / dV^T
+};
+
+template <int NDT, int NT>
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const AttnArgs a) {
+  constexpr int DK = 16 * NDT, MW = (NT + 1) / 2;
+  const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+  const int nqt = (a.Lq + 15) >> 4, nkt = (a.Lk + 15) >> 4, LQP = 16 * nqt;
+  const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+  if (item >= a.npairs * nkt) return;
+  const int pair = item / nkt, t = item - pair * nkt;
+  const int b = pair / a.H, h = pair - b * a.H;
+  const int Lq_e = a.nlive ? a.nlive[b] : a.Lq;
+  const int64_t drow0 = a.cstart ? (int64_t)a.cstart[b] : (int64_t)b * a.Lq;
+  const int64_t kin0 = a.kstart ? (int64_t)a.kstart[b] : (int64_t)b * a.Lk;
+  const int Lk_in = a.klen ? a.klen[b] : a.Lk;
+  const int Lk_e = a.kv_compact ? Lq_e : Lk_in;                               // key rows that exist in dk / dv
+  const int64_t krow0 = a.kv_compact ? drow0 : kin0;
+  if (16 * t >= Lk_e) return;          // dead keys have no row (and no gradient)
+  const int k = 16 * t + c16;
+  const bool inr = k < a.Lk;
+  // the query tiles that computed this key tile in launch 1 (same skip predicates by construction)
+  uint32_t rem = 0;
+  {
+    const uint32_t* vw = a.ws_use + (int64_t)pair * nqt;
+    const int Lq_x = Lq_e < a.Lq ? Lq_e : a.Lq;
+    const int nqt_e = (Lq_x + 15) >> 4;
+    for (int u = 0; u < nqt_e; ++u) rem |= ((vw[u] >> t) & 1u) << u;
+    rem = __builtin_amdgcn_readfirstlane(rem);
+  }
+  __shared__ __attribute__((aligned(16))) float tiles[4][2][16 * WaveTile<NDT>::SD];
+  const int wv = threadIdx.x >> 6;
+  const WaveTile<NDT> T0{tiles[wv][0]}, T1{tiles[wv][1]};
+  float4 bk[NDT], bv[NDT];
+  DkvBuf<NDT> b0;
+  {
+    DkvBuf<NDT>& kv = b0;
+    const char* kb0 = reinterpret_cast<const char*>(a.k + kin0 * a.ldk + h * DK);
+    const char* vb0 = reinterpret_cast<const char*>(a.v + kin0 * a.ldv + h * DK);
+    const int klast = Lk_in > 0 ? Lk_in - 1 : 0;
+    tile_load<NDT>(kv.tq, kb0, a.ldk, 16 * t, klast, g, c16);
+    tile_load<NDT>(kv.td, vb0, a.ldv, 16 * t, klast, g, c16);
+    T0.put(kv.tq, g, c16);
+    T1.put(kv.td, g, c16);
+    T0.get(bk, g, c16);
+    T1.get(bv, g, c16);
+  }
+  f32x4 vacc[NDT], kacc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) {
+    vacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    kacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int kw = t >> 1, kb = (t & 1) * 16 + c16;
+  const float4* meta = a.ws_meta + (int64_t)pair * LQP;
+  const uint32_t* kp = a.ws_keep + (int64_t)pair * LQP * MW + kw;
+  const uint32_t* mb = a.mbits ? a.mbits + (int64_t)b * a.mb_sb + kw : nullptr;
+  const char* qbase = reinterpret_cast<const char*>(a.q + (int64_t)b * a.Lq * a.ldq + h * DK);    // wave-uniform
+  const char* dbase = reinterpret_cast<const char*>(a.dout + drow0 * a.ldo + h * DK);
+  auto load = [&](DkvBuf<NDT>& B_, int u) {
+    tile_load<NDT>(B_.tq, qbase, a.ldq, 16 * u, a.Lq - 1, g, c16);
+    tile_load<NDT>(B_.td, dbase, a.ldo, 16 * u, Lq_e - 1, g, c16);
+  };
+  auto compute = [&](const DkvBuf<NDT>& B_, int u) {
+    // per-row scalars of rows 16u + 4g + r ({lse, delta, masked score, live}, mask / keep word of this key tile):
+    // small, L2-resident, requested here and consumed after the S / dP products
+    // ... one request per kind: lane (g, c16) asks for row 4g + (c16 & 3), so every quad of lanes holds the four rows
+    // of its group, and a quad broadcast (DPP, no memory traffic) hands each lane all four
+    float4 mt[4];
+    uint32_t mword[4], kword[4];
+    {
+      const int qq = 16 * u + 4 * g + (c16 & 3);
+      const int qc = qq < a.Lq ? qq : a.Lq - 1;
+      const float4 m1 = meta[qq];
+      const uint32_t w1 = mb ? mb[qc * a.mb_sq] : 0xffffffffu;
+      const uint32_t k1 = a.thr ? kp[qq * MW] : 0xffffffffu;
+#define GCT_QUAD(v, r) __builtin_amdgcn_mov_dpp((int)(v), (r) * 0x55, 0xf, 0xf, true)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        mt[r].x = __int_as_float(r == 0 ? GCT_QUAD(__float_as_int(m1.x), 0) : r == 1 ? GCT_QUAD(__float_as_int(m1.x), 1)
+                               : r == 2 ? GCT_QUAD(__float_as_int(m1.x), 2) : GCT_QUAD(__float_as_int(m1.x), 3));
+        mt[r].y = __int_as_float(r == 0 ? GCT_QUAD(__float_as_int(m1.y), 0) : r == 1 ? GCT_QUAD(__float_as_int(m1.y), 1)
+                               : r == 2 ? GCT_QUAD(__float_as_int(m1.y), 2) : GCT_QUAD(__float_as_int(m1.y), 3));
+        mt[r].z = __int_as_float(r == 0 ? GCT_QUAD(__float_as_int(m1.z), 0) : r == 1 ? GCT_QUAD(__float_as_int(m1.z), 1)
+                               : r == 2 ? GCT_QUAD(__float_as_int(m1.z), 2) : GCT_QUAD(__float_as_int(m1.z), 3));
+        mt[r].w = 0.f;
+        mword[r] = (uint32_t)(r == 0 ? GCT_QUAD(w1, 0) : r == 1 ? GCT_QUAD(w1, 1) : r == 2 ? GCT_QUAD(w1, 2) : GCT_QUAD(w1, 3));
+        kword[r] = (uint32_t)(r == 0 ? GCT_QUAD(k1, 0) : r == 1 ? GCT_QUAD(k1, 1) : r == 2 ? GCT_QUAD(k1, 2) : GCT_QUAD(k1, 3));
+      }
+#undef GCT_QUAD
+    }
+    f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, pa = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      float4 aq[NDT], ad[NDT];           // the same rows as row-per-lane fragments, through the wave's LDS tiles
+      T0.put(B_.tq, g, c16);
+      T1.put(B_.td, g, c16);
+      T0.get(aq, g, c16);
+      T1.get(ad, g, c16);
+      sa = dot_frag<NDT>(aq, bk, sa);   // S[q][k] (unscaled)
+      pa = dot_frag<NDT>(ad, bv, pa);   // dP[q][k]
+    }
+    float pd[4], ds[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = 16 * u + 4 * g + r;
+      // rows beyond Lq: their mask rows are all ones in launch 1, but nothing of theirs may reach dK / dV
+      const bool vis = qq < a.Lq && ((mword[r] >> kb) & 1u), keep = (kword[r] >> kb) & 1u, rreal = qq < Lq_e;
+      const float msk = (mt[r].z != 0.f || qq >= a.Lq) ? -1e9f : 0.f;
+      const float p = (inr && rreal) ? __expf(score_of(sa[r] * a.scale, true, vis, msk) - mt[r].x) : 0.f;
+      const float dpd = keep ? pa[r] * a.keep_scale : 0.f;
+      pd[r] = keep ? p * a.keep_scale : 0.f;
+      ds[r] = (inr && vis) ? p * (dpd - mt[r].y) : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        vacc[dt] = mfma16(vec_at<NDT>(B_.td[r], dt), pd[r], vacc[dt]);   // dV^T[d][k] += dO[q][d] Pd[q][k]
+        kacc[dt] = mfma16(vec_at<NDT>(B_.tq[r], dt), ds[r], kacc[dt]);   // dK^T[d][k] += Q[q][d] dS[q][k]
+      }
+    }
+  };
+  while (rem) {                        // wave-uniform
+    const int u0 = __builtin_ctz(rem);
+    rem &= rem - 1;
+    load(b0, u0);
+    compute(b0, u0);
+  }
+  if (k < Lk_e) {
+    char* vb = reinterpret_cast<char*>(a.dv + krow0 * a.lddv + h * DK);
+    char* kb_ = reinterpret_cast<char*>(a.dk + krow0 * a.lddk + h * DK);
+    const uint32_t voff = (uint32_t)((k * a.lddv + 4 * NDT * g) * 4), koff = (uint32_t)((k * a.lddk + 4 * NDT * g) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (NDT == 4) {
+        *reinterpret_cast<float4*>(vb + voff + 16 * i) = make_float4(vacc[0][i], vacc[1][i], vacc[2][i], vacc[3][i]);
+        *reinterpret_cast<float4*>(kb_ + koff + 16 * i) =
+            make_float4(kacc[0][i] * a.scale, kacc[1][i] * a.scale, kacc[2][i] * a.scale, kacc[3][i] * a.scale);
+      } else if constexpr (NDT == 2) {
+        *reinterpret_cast<float2*>(vb + voff + 8 * i) = make_float2(vacc[0][i], vacc[1][i]);
+        *reinterpret_cast<float2*>(kb_ + koff + 8 * i) = make_float2(kacc[0][i] * a.scale, kacc[1][i] * a.scale);
+      } else {
+        *reinterpret_cast<float*>(vb + voff + 4 * i) = vacc[0][i];
+        *reinterpret_cast<float*>(kb_ + koff + 4 * i) = kacc[0][i] * a.scale;
+      }
+    }
+  }
+}
+
 // one thread per packed word: bits[b][q][w] = OR_j (mask[b,q,32w+j] != 0) << j
 __global__ __launch_bounds__(256) void mask_pack_kernel(const uint8_t* __restrict__ mask, int64_t sb, int64_t sq, int B,
                                                         int rows, int Lk, uint32_t* __restrict__ bits) {
@@ -1013,7 +1381,7 @@ extern "C" int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t
   a.kstart = kstart; a.klen = klen;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.npairs = B * H; a.scale = scale;
   a.thr = gct_drop_threshold(p); a.keep_scale = 1.0f / (1.0f - p); a.rng = gct_rng_make(seed, site);
-  const int LQP = (Lq + 15) & ~15, LKP = (Lk + 15) & ~15, SD = dk + 4;
+  const int LKP = (Lk + 15) & ~15, SD = dk + 4;
   const int nt = LKP / 16;                      // query tiles beyond the wave count are looped
   const size_t lds = (size_t)(2 * LKP) * SD * 4;
   GCT_CHECK_ARG(lds <= 160 * 1024, "attn_fwd: needs %zu B of LDS", lds);
@@ -1025,6 +1393,14 @@ extern "C" int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t
   return GCT_OK;
 }
 
+// workspace of the direct backward kernels (L_k <= 96): per (pair, padded query row) a float4 record and 3 keep words,
+// per (pair, query tile) one word; without it (or beyond 96 keys) gct_attn_bwd runs the LDS kernel
+extern "C" int64_t gct_attn_bwd_ws_bytes(int B, int H, int Lq, int Lk) {
+  if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || Lk > 96) return 0;
+  const int64_t LQP = (Lq + 15) & ~15, rows = (int64_t)B * H * LQP;
+  return rows * 16 + rows * 3 * 4 + (((int64_t)B * H * (LQP / 16) * 4 + 15) & ~(int64_t)15);
+}
+
 extern "C" int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk,
                             const float* v, int64_t ldv, const uint32_t* mbits, int64_t mb_sb,
                             int64_t mb_sq, const float* o, const float* dout, int64_t ldo,
@@ -1032,7 +1408,7 @@ extern "C" int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t
                             int64_t lddk, float* dv, int64_t lddv, int B, int H, int Lq, int Lk,
                             int dk, float scale, float p, uint64_t seed, uint32_t site,
                             const int32_t* cstart, const int32_t* nlive, int kv_compact,
-                            const int32_t* kstart, const int32_t* klen, void* stream) {
+                            const int32_t* kstart, const int32_t* klen, void* ws, int64_t ws_bytes, void* stream) {
   int rc = check_common("attn_bwd", q, ldq, k, ldk, v, ldv, mbits, mb_sb, mb_sq, B, H, Lq, Lk, dk, p);
   if (rc) return rc;
   GCT_CHECK_ARG(o && dout && lse && dq && dk_ && dv, "attn_bwd: null pointer");
@@ -1059,12 +1435,35 @@ extern "C" int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t
   const int LQP = (Lq + 15) & ~15, LKP = (Lk + 15) & ~15, SD = dk + 4;
   const int LMX = LQP > LKP ? LQP : LKP, nt = LMX / 16;
   const int MW = nt <= 6 ? 3 : nt <= 8 ? 4 : 7;
+  hipStream_t st = (hipStream_t)stream;
+  static const bool lds_kernel = getenv("GCT_ATTN_BWD_LDS") != nullptr;       // A/B switch for benchmarks
+  if (LKP <= 96 && ws && !lds_kernel && gct_aligned16(ws) && ws_bytes >= gct_attn_bwd_ws_bytes(B, H, Lq, Lk)) {
+    // direct kernels: one wave per (pair, query tile), then one wave per (pair, key tile)
+    const int64_t rows = (int64_t)a.npairs * LQP;
+    a.ws_meta = reinterpret_cast<float4*>(ws);
+    a.ws_keep = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ws) + rows * 16);
+    a.ws_use = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ws) + rows * 16 + rows * 3 * 4);
+    const int64_t items_q = (int64_t)a.npairs * (LQP / 16), items_k = (int64_t)a.npairs * (LKP / 16);
+    GCT_CHECK_ARG((items_q + 3) / 4 <= INT32_MAX && (items_k + 3) / 4 <= INT32_MAX, "attn_bwd: grid too large");
+    const dim3 gq((unsigned)((items_q + 3) / 4)), gk((unsigned)((items_k + 3) / 4));
+    if (dk == 64) {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 6>), gq, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 6>), gk, dim3(256), 0, st, a);
+    } else if (dk == 32) {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 6>), gq, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, 6>), gk, dim3(256), 0, st, a);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<1, 6>), gq, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<1, 6>), gk, dim3(256), 0, st, a);
+    }
+    GCT_LAUNCH_CHECK("attn_bwd (direct)");
+    return GCT_OK;
+  }
   const size_t lds = (size_t)(2 * LMX) * SD * 4 + (size_t)LQP * 8 + (size_t)LQP * MW * 8 + (size_t)LQP * 2;
   GCT_CHECK_ARG(lds <= 160 * 1024, "attn_bwd: needs %zu B of LDS", lds);
   const int per_cu = lds <= 50 * 1024 ? 3 : lds <= 76 * 1024 ? 2 : 1;
   const int64_t want = (int64_t)num_cus() * per_cu * 2;            // a few pairs per workgroup keep the tail short
   const unsigned grid = (unsigned)(a.npairs < want ? a.npairs : want);
-  hipStream_t st = (hipStream_t)stream;
   rc = nt <= 6 ? launch_bwd_dk<6>(dk, a, lds, grid, st) : nt <= 8 ? launch_bwd_dk<8>(dk, a, lds, grid, st)
                                                                   : launch_bwd_dk<13>(dk, a, lds, grid, st);
   if (rc) return rc;

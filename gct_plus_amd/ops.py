@@ -483,8 +483,10 @@ def pack_mask(mask, B, Lq, Lk) -> Optional["MaskBits"]:
 
 
 def _mb(mask, B, Lq, Lk):
+    """(pointer, batch stride, row stride, owner): the caller keeps `owner` referenced until its launch is enqueued --
+    a mask packed on the fly lives only in that object, and a freed block may be handed to the next torch.empty."""
     mb = pack_mask(mask, B, Lq, Lk)
-    return (None, 0, 0) if mb is None else (mb.bits.data_ptr(), mb.sb, mb.sq)
+    return (None, 0, 0, None) if mb is None else (mb.bits.data_ptr(), mb.sb, mb.sq, mb)
 
 
 def attn_fwd(q, k, v, ld_q, ld_k, ld_v, mask, B, H, Lq, Lk, dk, p, seed, site, out=None,
@@ -495,25 +497,44 @@ def attn_fwd(q, k, v, ld_q, ld_k, ld_v, mask, B, H, Lq, Lk, dk, p, seed, site, o
     o = torch.empty(B * Lq, H * dk, dtype=torch.float32, device=dev) if out is None else out
     lse = torch.empty(B * H * Lq, dtype=torch.float32, device=dev)
     probs = torch.empty(B, H, Lq, Lk, dtype=torch.float32, device=dev) if want_probs else None
-    mp, sb, sq = _mb(mask, B, Lq, Lk)
+    mp, sb, sq, mask_owner = _mb(mask, B, Lq, Lk)
     check(_L().gct_attn_fwd(_p(q), ld_q, _p(k), ld_k, _p(v), ld_v, mp, sb, sq, _p(o),
                             o.stride(0), _p(lse), _p(probs), B, H, Lq, Lk, dk,
                             1.0 / math.sqrt(dk), p, seed, site, None if keys is None else _p(keys.cstart),
                             None if keys is None else _p(keys.n_b), _st()), "gct_attn_fwd")
+    del mask_owner
     return o, lse, probs
+
+
+_ATTN_BWD_WS = {}
+
+
+def _attn_bwd_ws(dev, nbytes):
+    """Scratch of the two-launch attention backward: one buffer per device, grown on demand (launches on one
+    stream are ordered, so consecutive calls may share it)."""
+    if nbytes <= 0:
+        return None
+    ws = _ATTN_BWD_WS.get(dev)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _ATTN_BWD_WS[dev] = ws
+    return ws
 
 
 def attn_bwd(q, k, v, ld_q, ld_k, ld_v, mask, o, dout, lse, dq, dk_, dv, ld_dq, ld_dk, ld_dv,
              B, H, Lq, Lk, dk, p, seed, site, live=None, kv_compact=False, keys=None):
     """live (LiveRows): dout / dq are quad-compacted; kv_compact: so are dk / dv (self-attention); keys (KeyRows):
     k / v / dk / dv hold the visible keys only (cross-attention)."""
-    mp, sb, sq = _mb(mask, B, Lq, Lk)
+    ws = _attn_bwd_ws(q.device, int(_L().gct_attn_bwd_ws_bytes(B, H, Lq, Lk)))
+    mp, sb, sq, mask_owner = _mb(mask, B, Lq, Lk)
     check(_L().gct_attn_bwd(_p(q), ld_q, _p(k), ld_k, _p(v), ld_v, mp, sb, sq, _p(o),
                             _p(dout), o.stride(0), _p(lse), _p(dq), ld_dq, _p(dk_), ld_dk,
                             _p(dv), ld_dv, B, H, Lq, Lk, dk, 1.0 / math.sqrt(dk), p, seed, site,
                             None if live is None else _p(live.cstart), None if live is None else _p(live.n_b),
                             int(bool(kv_compact)), None if keys is None else _p(keys.cstart),
-                            None if keys is None else _p(keys.n_b), _st()), "gct_attn_bwd")
+                            None if keys is None else _p(keys.n_b), _p(ws), 0 if ws is None else ws.numel(),
+                            _st()), "gct_attn_bwd")
+    del mask_owner
 
 
 def _mask_strides(mask_u8, B, Lq, Lk):

@@ -37,7 +37,7 @@ extern "C" {
 #define GCT_ERR_ARG (-1)  /* bad shape / alignment / null pointer            */
 #define GCT_ERR_HIP (-2)  /* a HIP runtime call failed (launch error)        */
 
-#define GCT_ABI_VERSION 4
+#define GCT_ABI_VERSION 5
 
 int gct_version(void);
 const char* gct_last_error(void);
@@ -256,8 +256,12 @@ int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const
                  float* dq, int64_t lddq, float* dk_, int64_t lddk, float* dv, int64_t lddv,
                  int B, int H, int Lq, int Lk, int dk, float scale, float p, uint64_t seed,
                  uint32_t site, const int32_t* cstart, const int32_t* nlive, int kv_compact,
-                 const int32_t* kstart, const int32_t* klen, void* stream);
-/* kstart / klen as in gct_attn_fwd: k, v AND dk, dv hold the visible keys only (excludes kv_compact). */
+                 const int32_t* kstart, const int32_t* klen, void* ws, int64_t ws_bytes, void* stream);
+/* kstart / klen as in gct_attn_fwd: k, v AND dk, dv hold the visible keys only (excludes kv_compact).
+ * ws (nullable, caller-owned, 16-B aligned, >= gct_attn_bwd_ws_bytes): scratch of the two-launch backward used for
+ * Lk <= 96 (one wave per query tile -> dq, then one wave per key tile -> dk, dv; no LDS); without it, or beyond 96
+ * keys, the single-launch LDS kernel runs.  Same results either way (same arithmetic, same dropout bits). */
+int64_t gct_attn_bwd_ws_bytes(int B, int H, int Lq, int Lk);
 
 /* ------------------------------------------------- K6: reparameterisation + KL */
 /* Model/sublayers.py:14-20 / Model/cvaetf.py:63-69: z = eps*exp(0.5*log_var)+mu.
