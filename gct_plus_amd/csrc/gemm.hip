@@ -1083,6 +1083,40 @@ int launch_x6_tail_split(const GemmArgs& g, hipStream_t st, float* ws, int64_t w
   return GCT_OK;
 }
 
+// Few 128x256 tiles but a long reduction (FFN-2 of a 1 024 .. 8 192-row decode step: 32-64 tiles, K = 2 048): the bf16x6
+// kernel with K split s ways into fp32 slabs + the fix-up kernel fills the chip where the plain launch would use a
+// quarter of it and the skinny fp32 kernel would run at the fp32 pipe's rate.  Returns 1 if it took the launch.
+// number of K-splits of that route (1 = not taken); shared with gct_linear_fwd_ws_bytes
+int x6_splitk_all_plan(int64_t M, int64_t N, int64_t K) {
+  constexpr int64_t CUS = 256;
+  const int64_t tiles = ((M + XBM - 1) / XBM) * ((N + XBN - 1) / XBN), nkt = K / XBK;
+  if (tiles > CUS / 2 || K % XBK != 0 || nkt < 32 || M < 1024) return 1;
+  int64_t sp = CUS / tiles;
+  if (sp > nkt / 8) sp = nkt / 8;                      // >= 8 K-tiles per split
+  if (sp > 8) sp = 8;
+  return sp < 2 ? 1 : (int)sp;
+}
+template <int MODE>
+int launch_x6_splitk_all(const GemmArgs& g, hipStream_t st, float* ws, int64_t ws_bytes, int* taken) {
+  *taken = 0;
+  if (MODE != X6_FWD || g.nsplit != 1 || !ws || !gct_aligned16(ws)) return GCT_OK;
+  const int64_t sp = x6_splitk_all_plan(g.M, g.N, g.K), nkt = g.K / XBK;
+  if (sp < 2 || sp * g.M * g.N * (int64_t)sizeof(float) > ws_bytes) return GCT_OK;
+  GemmArgs p = g;
+  p.ksplit = ((nkt + sp - 1) / sp) * XBK;
+  p.nsplit = (int)((g.K + p.ksplit - 1) / p.ksplit);
+  p.epi = EPI_SLAB; p.c0 = ws; p.ldc = g.N; p.slab_stride = g.M * g.N;
+  p.c_d1 = p.c_d2 = 0; p.c_nper = INT64_MAX / 4; p.bias0 = nullptr; p.resid = nullptr; p.pre = nullptr; p.pre_in = nullptr;
+  int rc = launch_x6<MODE>(p, st);
+  if (rc) return rc;
+  const int64_t patches = ((g.M + 3) / 4) * (g.N / 4);
+  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((patches + 255) / 256)), dim3(256), 0, st, g,
+                     (const float*)ws, p.nsplit, p.slab_stride);
+  GCT_LAUNCH_CHECK("x6 split-K fix-up");
+  *taken = 1;
+  return GCT_OK;
+}
+
 template <bool A_KC, bool B_KC>
 int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullptr, int64_t ws_bytes = 0) {
   const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.nsplit;
@@ -1094,6 +1128,16 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
   dim3 grid((unsigned)tiles), block(256);
   const bool fast = fast_ok<A_KC, B_KC>(g, vec);
   static const int stagger_env = getenv("GCT_GEMM_STAGGER") ? atoi(getenv("GCT_GEMM_STAGGER")) : -1;
+  if (A_KC && B_KC && gemm_mode() == GCT_GEMM_BF16X6 && g.epi < EPI_D0) {
+    if (x6_ok<X6_FWD>(g, vec)) {
+      int taken = 0;
+      const int rc = launch_x6_splitk_all<X6_FWD>(g, st, skinny_ws, ws_bytes, &taken);
+      if (rc || taken) {
+        if (taken) ++g_gemm_launches[1];
+        return rc;
+      }
+    }
+  }
   // skinny M (decode steps): 64x64 tiles when the 128x128 grid would leave most CUs idle
   if (fast && A_KC && B_KC && g.nsplit == 1 && tiles < 192 && g.epi < EPI_D0 &&
       (g.b_nper >= g.N || g.b_nper % 64 == 0)) {
@@ -1295,6 +1339,8 @@ extern "C" int64_t gct_linear_fwd_ws_bytes(int64_t M, int K, int Ntot) {
     const int s = x6_tail_plan(M, Ntot, K, &m1);
     if (s > 1) need = (int64_t)s * (M - m1) * Ntot * (int64_t)sizeof(float);
   }
+  const int64_t sp = x6_splitk_all_plan(M, Ntot, K);   // bf16x6 split-K over the whole problem (few tiles, long K)
+  if (sp > 1 && sp * M * Ntot * (int64_t)sizeof(float) > need) need = sp * M * Ntot * (int64_t)sizeof(float);
   return need + 256;
 }
 

@@ -585,6 +585,36 @@ def test_linear_bf16x6_epilogues_and_dropout_masks(ops, M, N):
         close(c[i], a[i].double(), 5e-5, 1e-4, what)
 
 
+def test_linear_bf16x6_split_k_over_the_whole_problem(ops):
+    """Few 128x256 tiles and a long reduction (FFN-2 of a decode step with >= 1 024 rows): with a workspace the bf16x6
+    kernel runs with K split into slabs + the fix-up kernel (which applies the fused epilogue).  Same dropout mask and
+    values as the fp32-mode launch, values vs fp64."""
+    M, K, N, p, seed = 1024, 2048, 512, 0.1, 5
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    xg, bg, rg = x.to(DEV), b.to(DEV), r.to(DEV)
+    flat, (wg,) = _planes_for(ops, [w])
+    ws = torch.empty(int(ops._L().gct_linear_fwd_ws_bytes(M, K, N)) // 4 + 64, device=DEV)
+    out = {}
+    try:
+        for mode in (ops.GEMM_F32, ops.GEMM_BF16X6):
+            ops.gemm_set_mode(mode)
+            y1, y2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+            c0, k0 = ops.gemm_launch_counts(), ops._L().gct_gemm_x6_kernel_launches()
+            ops.linear_fwd(xg, [wg], [bg], [y1], N, ws=ws)
+            ops.linear_fwd(xg, [wg], [bg], [y2], N, epi=ops.EPI_DROP_RESID, resid=rg, p=p, seed=seed, site=4, ws=ws)
+            if mode == ops.GEMM_BF16X6:            # both calls took the bf16x6 kernel (one split launch each)
+                assert ops.gemm_launch_counts()[1] == c0[1] + 2 and ops._L().gct_gemm_x6_kernel_launches() == k0 + 2
+            out[mode] = (y1.cpu(), y2.cpu())
+    finally:
+        ops.gemm_set_mode(ops.GEMM_BF16X6)
+        ops.unregister_planes(flat)
+    u = x.double() @ w.double().t() + b.double()
+    close(out[ops.GEMM_BF16X6][0], u, 2e-5, 2e-5, "split-K bf16x6 vs fp64")
+    a, c = out[ops.GEMM_F32][1], out[ops.GEMM_BF16X6][1]
+    assert torch.equal(a == r, c == r)             # same dropped positions (a dropped element leaves the residual)
+    close(c, a.double(), 5e-5, 1e-4, "dropout + residual through the fix-up kernel")
+
+
 def test_wgrad_over_nonzero_row_tiles(ops):
     """gct_nonzero_row_tiles + gct_linear_wgrad_kt: reducing only over the 32-row token tiles whose gradient rows
     are not all zero gives the dense result (the skipped terms are exact zeros)."""
