@@ -20,7 +20,9 @@ import re
 
 SHORT = [(r"gemm_x6_kernel<0>", "gemm_x6_kernel<0> (forward)"), (r"gemm_x6_kernel<1>", "gemm_x6_kernel<1> (dgrad)"),
          (r"gemm_x6_kernel<2>", "gemm_x6_kernel<2> (wgrad)"), (r"attn_fwd_kernel<4", "attn_fwd_kernel<4,..>"),
-         (r"attn_bwd_kernel<4", "attn_bwd_kernel<4,..>"), (r"norm_fwd_kernel", "norm_fwd_kernel"),
+         (r"attn_bwd_kernel<4", "attn_bwd_kernel<4,..>"), (r"attn_fwd_direct_kernel<4", "attn_fwd_direct_kernel<4,6>"),
+         (r"attn_bwd_dq_kernel<4", "attn_bwd_dq_kernel<4,6>"), (r"attn_bwd_dkv_kernel<4", "attn_bwd_dkv_kernel<4,6>"),
+         (r"norm_fwd_kernel", "norm_fwd_kernel"),
          (r"norm_bwd_kernel", "norm_bwd_kernel"), (r"adam_kernel", "adam_kernel"),
          (r"gather_quads_kernel", "gather_quads_kernel"), (r"dropout_bwd_kernel", "dropout_bwd_kernel"),
          (r"gemm_f32_fast_kernel", "gemm_f32_fast_kernel"), (r"embed_pe_bwd_kernel", "embed_pe_bwd_kernel")]
