@@ -51,12 +51,12 @@ SIGNATURES = {
                                   P, P, P, P]),
     "gct_dropout_bwd": (I32, [P, P, I64, I32, F32, U64, U32, P, P]),
     "gct_attn_fwd": (I32, [P, I64, P, I64, P, I64, P, I64, I64, P, I64, P, P, I32, I32, I32, I32,
-                           I32, F32, F32, U64, U32, P, P, P]),
+                           I32, F32, F32, U64, U32, P, P, P, I64, I64, P]),
     "gct_attn_bwd": (I32, [P, I64, P, I64, P, I64, P, I64, I64, P, P, I64, P, P, I64, P, I64,
-                           P, I64, I32, I32, I32, I32, I32, F32, F32, U64, U32, P, P, I32, P, P, P, I64, P]),
+                           P, I64, I32, I32, I32, I32, I32, F32, F32, U64, U32, P, P, I32, P, P, P, I64, I64, P, I64, P]),
     "gct_attn_bwd_ws_bytes": (I64, [I32, I32, I32, I32]),
     "gct_key_rows": (I32, [P, I64, I32, I32, P, P, P, P, P, P, P]),
-    "gct_attn_mask_pack": (I32, [P, I64, I64, I32, I32, I32, P, P]),
+    "gct_attn_mask_pack": (I32, [P, I64, I64, I32, I32, I32, P, P, P]),
     "gct_reparam_fwd": (I32, [P, P, P, P, P, I64, U64, U32, P]),
     "gct_reparam_bwd": (I32, [P, P, P, P, P, P, P, I64, P]),
     "gct_kld_fwd": (I32, [P, P, P, P, I64, P]),
@@ -77,7 +77,7 @@ SIGNATURES = {
     "gct_add": (I32, [P, P, P, I64, P]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 

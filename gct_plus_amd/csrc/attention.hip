@@ -49,6 +49,10 @@ struct AttnArgs {
   int ldq, ldk, ldv;
   const uint32_t* mbits;               // packed mask rows (nullable = everything visible)
   int mb_sb, mb_sq;                    // strides in words: per batch, per query row (0: key-padding mask)
+  // visible key tiles per (batch, 16-row query tile), precomputed by gct_attn_mask_pack (nullable: computed from the
+  // mask rows by every wave -- a dependent load + ~80 VALU before the first K request can go out)
+  const uint32_t* tbits;
+  int tb_sb, tb_su;                    // strides in words: per batch, per query tile (0: key-padding mask)
   float* o;
   int ldo;
   float* lse;
@@ -96,10 +100,18 @@ struct AttnArgs {
 #define ASTAMP_OUT                                                                     \
   if (a.stamps && (threadIdx.x & 63) == 0 && blockIdx.x < 64)                          \
     for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * (ATT_THREADS / 64) + (threadIdx.x >> 6)) * 8 + i] = seg[i]
+// direct kernels: one record per wave (= item), items [GCT_STAMP_ITEM0, GCT_STAMP_ITEM0 + 4096)
+#define GCT_STAMP_ITEM0 8192
+#define DSTAMP_OUT_AT(item, rec0)                                                      \
+  if (a.stamps && (threadIdx.x & 63) == 0 && (item) >= GCT_STAMP_ITEM0 && (item) < GCT_STAMP_ITEM0 + 4096)  \
+    for (int i = 0; i < 8; ++i) a.stamps[((size_t)((item) - GCT_STAMP_ITEM0 + (rec0))) * 8 + i] = seg[i]
+#define DSTAMP_OUT(item) DSTAMP_OUT_AT(item, 0)
 #else
 #define ASTAMP_DECL
 #define ASTAMP(i)
 #define ASTAMP_OUT
+#define DSTAMP_OUT(item)
+#define DSTAMP_OUT_AT(item, rec0)
 #endif
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -508,6 +520,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs 
   const int nqt = (a.Lq + 15) >> 4, nkt = (a.Lk + 15) >> 4;
   const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
   if (item >= a.npairs * nqt) return;
+  ASTAMP_DECL;
   const int pair = item / nqt, u = item - pair * nqt;
   const int b = pair / a.H, h = pair - b * a.H;
   const int q = 16 * u + c16;
@@ -523,20 +536,32 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs 
   tile_load<NDT>(tq, reinterpret_cast<const char*>(a.q + (int64_t)b * a.Lq * a.ldq + h * DK), a.ldq, 16 * u, a.Lq - 1, g, c16);
   uint4 mraw[(MW + 3) / 4] = {};
   if (a.mbits) mask_row_raw<MW>(mraw, a, b, q);
+  const char* kbase = reinterpret_cast<const char*>(a.k + kr0 * a.ldk + h * DK);                  // wave-uniform
+  VT tk[NT][4];
+  // with the precomputed tile word (a scalar load) the K requests go out before the mask rows are back
+  uint32_t use = 0;
+  if (a.tbits) {
+    use = __builtin_amdgcn_readfirstlane(a.tbits[(int64_t)b * a.tb_sb + u * a.tb_su]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if ((use >> t) & 1u) tile_load<NDT>(tk[t], kbase, a.ldk, 16 * t, klast, g, c16);
+  }
   uint32_t mw[MW];
   mask_row_use<MW>(mw, mraw, a, q);
-  const uint32_t use = tiles_for_q<MW>(mw, q, a.Lq, a.Lk, nkt);
+  if (!a.tbits) {
+    use = tiles_for_q<MW>(mw, q, a.Lq, a.Lk, nkt);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if ((use >> t) & 1u) tile_load<NDT>(tk[t], kbase, a.ldk, 16 * t, klast, g, c16);
+  }
+  ASTAMP(0);                           // Q / mask / K requests, mask arrival (visible tiles when not precomputed)
   uint32_t rowvis = 0;
 #pragma unroll
   for (int w = 0; w < MW; ++w) rowvis |= mw[w] & range_word(w, a.Lk);
-  const char* kbase = reinterpret_cast<const char*>(a.k + kr0 * a.ldk + h * DK);                  // wave-uniform
-  VT tk[NT][4];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-    if ((use >> t) & 1u) tile_load<NDT>(tk[t], kbase, a.ldk, 16 * t, klast, g, c16);
   float4 bq[NDT];
   T1.put(tq, g, c16);
   T1.get(bq, g, c16);
+  ASTAMP(1);                           // K requests, Q arrival -> LDS -> fragment
   f32x4 sacc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -553,6 +578,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs 
       }
       sacc[t] = dot_frag<NDT>(ak, bq, sacc[t]);
     }
+  ASTAMP(2);                           // K arrival -> LDS -> fragments, S^T issued
   // V fragments, requested now and consumed after the softmax: lane (c16, g) holds V[16t + 4g + r][NDT c16 .. + NDT)
   // -- output tile dt of the P.V product covers the head columns {NDT m + dt}
   const char* vbase = reinterpret_cast<const char*>(a.v + kr0 * a.ldv + h * DK);                  // wave-uniform
@@ -567,6 +593,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs 
         av[t][r] = *reinterpret_cast<const VT*>(vbase + (uint32_t)((rr * a.ldv + NDT * c16) * 4));
       }
     }
+  ASTAMP(3);                           // V requests
   // scale + mask + softmax (as fwd_unit)
   float m = -INFINITY;
 #pragma unroll
@@ -620,6 +647,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs 
         sacc[t][r] = ((keep >> (4 * t + r)) & 1ull) ? p * a.keep_scale : 0.f;
       }
     }
+  ASTAMP(4);                           // S^T results, softmax, dropout bits
   // O^T[m][q] (tile dt) = sum_k V[k][NDT m + dt] * Pdrop^T[k][q]
   f32x4 oacc[NDT];
 #pragma unroll
@@ -633,6 +661,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs 
         for (int dt = 0; dt < NDT; ++dt) oacc[dt] = mfma16(vec_at<NDT>(av[t][r], dt), sacc[t][r], oacc[dt]);
       }
     }
+  ASTAMP(5);                           // V arrival, P.V issued
   if (q < a.Lq) {
     char* obase = reinterpret_cast<char*>(a.o + (int64_t)b * a.Lq * a.ldo + h * DK);             // wave-uniform
     const uint32_t ooff = (uint32_t)((q * a.ldo + 4 * NDT * g) * 4);
@@ -646,6 +675,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs 
         *reinterpret_cast<float*>(obase + ooff + 4 * i) = oacc[0][i];
     }
   }
+  ASTAMP(6);                           // P.V results, store
+  DSTAMP_OUT(item);
 }
 
 // ----------------------------------------------------------------------------- backward
@@ -951,6 +982,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const AttnArgs a) {
   const int nqt = (a.Lq + 15) >> 4, nkt = (a.Lk + 15) >> 4, LQP = 16 * nqt;
   const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
   if (item >= a.npairs * nqt) return;
+  ASTAMP_DECL;
   const int pair = item / nqt, u = item - pair * nqt;
   const int b = pair / a.H, h = pair - b * a.H;
   const int64_t lrow0 = (int64_t)pair * a.Lq;
@@ -998,6 +1030,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const AttnArgs a) {
       nz |= (bd[j].x != 0.f) | (bd[j].y != 0.f) | (bd[j].z != 0.f) | (bd[j].w != 0.f);
     }
   }
+  ASTAMP(0);                           // Q / dO / O requests -> arrival -> LDS -> fragments, delta partials
   del += __shfl_xor(del, 16, 64);
   del += __shfl_xor(del, 32, 64);
   nz |= __shfl_xor(nz, 16, 64);
@@ -1023,9 +1056,11 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const AttnArgs a) {
     }
     return;
   }
-  const uint32_t use = tiles_for_q<MW>(mw, q, a.Lq, a.Lk, nkt);
+  const uint32_t use = a.tbits ? __builtin_amdgcn_readfirstlane(a.tbits[(int64_t)b * a.tb_sb + u * a.tb_su])
+                               : tiles_for_q<MW>(mw, q, a.Lq, a.Lk, nkt);
   if (lane == 0) *visit = use;
   const uint64_t keepw = keep_bits_row<NT>(a, (uint32_t)(lrow0 + q), use, g);
+  ASTAMP(1);                           // mask arrival, row scalars, visible tiles, dropout bits
   uint16_t* kp_h = reinterpret_cast<uint16_t*>(a.ws_keep + ((int64_t)pair * LQP + q) * MW);
   const char* kbase = reinterpret_cast<const char*>(a.k + kin0 * a.ldk + h * DK);                 // wave-uniform
   const char* vbase = reinterpret_cast<const char*>(a.v + kin0 * a.ldv + h * DK);
@@ -1040,6 +1075,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const AttnArgs a) {
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) qacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto compute = [&](const DqBuf<NDT>& B_, int t) {
+    ASTAMP(2);                         // (K / V requests issued)
     f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f}, pacc = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
       float4 ak[NDT], av[NDT];                   // K / V rows 16t + c16 as row-per-lane fragments
@@ -1050,6 +1086,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const AttnArgs a) {
       sacc = dot_frag<NDT>(ak, bq, sacc);        // S^T (unscaled)
       pacc = dot_frag<NDT>(av, bd, pacc);        // dP^T
     }
+    ASTAMP(3);                         // K / V arrival -> LDS -> fragments, S^T / dP^T issued
     uint32_t word = mw[0];
 #pragma unroll
     for (int w = 1; w < MW; ++w) word = (t >> 1) == w ? mw[w] : word;
@@ -1069,12 +1106,14 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const AttnArgs a) {
       const float dpd = ((keep >> r) & 1u) ? pacc[r] * a.keep_scale : 0.f;
       ds[r] = (inr && vis) ? p * (dpd - del) : 0.f;            // dS^T (masked_fill passes no grad)
     }
+    ASTAMP(4);                         // S^T / dP^T results, dS arithmetic
     // dQ^T[m][q] (tile dt) += sum_k K[k][NDT m + dt] dS^T[k][q]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) qacc[dt] = mfma16(vec_at<NDT>(B_.kt[r], dt), ds[r], qacc[dt]);
     }
+    ASTAMP(5);                         // dQ issued
   };
   for (uint32_t rem = use; rem; rem &= rem - 1) {       // wave-uniform
     const int t0 = __builtin_ctz(rem);
@@ -1093,6 +1132,8 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const AttnArgs a) {
         *reinterpret_cast<float*>(dbase + doff + 4 * i) = qacc[0][i] * a.scale;
     }
   }
+  ASTAMP(6);                           // dQ results, store
+  DSTAMP_OUT_AT(item, 4096);          // (records 4096.. : launch 2 writes 0..4095)
 }
 
 template <int NDT>
@@ -1107,6 +1148,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const AttnArgs a) 
   const int nqt = (a.Lq + 15) >> 4, nkt = (a.Lk + 15) >> 4, LQP = 16 * nqt;
   const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
   if (item >= a.npairs * nkt) return;
+  ASTAMP_DECL;
   const int pair = item / nkt, t = item - pair * nkt;
   const int b = pair / a.H, h = pair - b * a.H;
   const int Lq_e = a.nlive ? a.nlive[b] : a.Lq;
@@ -1144,6 +1186,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const AttnArgs a) 
     T0.get(bk, g, c16);
     T1.get(bv, g, c16);
   }
+  ASTAMP(0);                           // visit list, K / V requests -> arrival -> LDS -> fragments
   f32x4 vacc[NDT], kacc[NDT];
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) {
@@ -1188,6 +1231,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const AttnArgs a) 
       }
 #undef GCT_QUAD
     }
+    ASTAMP(1);                         // Q / dO tile + row scalar requests issued
     f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, pa = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
       float4 aq[NDT], ad[NDT];           // the same rows as row-per-lane fragments, through the wave's LDS tiles
@@ -1198,6 +1242,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const AttnArgs a) 
       sa = dot_frag<NDT>(aq, bk, sa);   // S[q][k] (unscaled)
       pa = dot_frag<NDT>(ad, bv, pa);   // dP[q][k]
     }
+    ASTAMP(2);                         // Q / dO arrival -> LDS -> fragments, S / dP issued
     float pd[4], ds[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1210,6 +1255,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const AttnArgs a) 
       pd[r] = keep ? p * a.keep_scale : 0.f;
       ds[r] = (inr && vis) ? p * (dpd - mt[r].y) : 0.f;
     }
+    ASTAMP(3);                         // row scalars, S / dP results, P / dS arithmetic
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -1218,6 +1264,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const AttnArgs a) 
         kacc[dt] = mfma16(vec_at<NDT>(B_.tq[r], dt), ds[r], kacc[dt]);   // dK^T[d][k] += Q[q][d] dS[q][k]
       }
     }
+    ASTAMP(4);                         // dV / dK issued
   };
   while (rem) {                        // wave-uniform
     const int u0 = __builtin_ctz(rem);
@@ -1244,6 +1291,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const AttnArgs a) 
       }
     }
   }
+  ASTAMP(5);                           // dV / dK results, store
+  DSTAMP_OUT(item);
 }
 
 // one thread per packed word: bits[b][q][w] = OR_j (mask[b,q,32w+j] != 0) << j
@@ -1261,6 +1310,26 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const uint8_t* __restric
     if (k < Lk && m[k]) word |= 1u << j;
   }
   bits[i] = word;
+}
+
+#ifdef GCT_STAMPS
+unsigned long long* g_attn_stamps = nullptr;   // tools/attn_stamps.hip
+#endif
+// one wave per (batch, query tile): the word tiles_for_q would compute (bit t: key tile t must be visited)
+__global__ __launch_bounds__(256) void mask_tiles_kernel(const uint32_t* __restrict__ bits, int mb_sb, int mb_sq, int B,
+                                                         int ntr, int Lq, int Lk, uint32_t* __restrict__ tiles) {
+  const int lane = threadIdx.x & 63, c16 = lane & 15;
+  const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+  if (item >= B * ntr) return;
+  const int b = item / ntr, u = item - b * ntr;
+  // key-padding mask (one row per batch): every query row is that row, whatever Lq is
+  const int q = mb_sq ? 16 * u + c16 : 0, lq = mb_sq ? Lq : 1;
+  const int qq = q < lq ? q : lq - 1;
+  uint32_t mw[MASK_W];
+#pragma unroll
+  for (int w = 0; w < MASK_W; ++w) mw[w] = q < lq ? bits[(int64_t)b * mb_sb + (int64_t)qq * mb_sq + w] : 0xffffffffu;
+  const uint32_t use = tiles_for_q<MASK_W>(mw, q, lq, Lk, (Lk + 15) >> 4);
+  if (lane == 0) tiles[item] = use;
 }
 
 int g_num_cus = 0;
@@ -1352,7 +1421,7 @@ int launch_bwd_dk(int dk, const AttnArgs& a, size_t lds, unsigned grid, hipStrea
 }  // namespace
 
 extern "C" int gct_attn_mask_pack(const uint8_t* mask, int64_t mask_sb, int64_t mask_sq, int B, int Lq, int Lk,
-                                  uint32_t* bits, void* stream) {
+                                  uint32_t* bits, uint32_t* tiles, void* stream) {
   GCT_CHECK_ARG(mask && bits && B >= 0 && Lq > 0 && Lk > 0 && Lk <= 32 * MASK_W && gct_aligned16(bits),
                 "attn_mask_pack: bad args (Lk <= %d)", 32 * MASK_W);
   const int rows = mask_sq == 0 ? 1 : Lq;           // key-padding mask: one row per batch
@@ -1361,6 +1430,13 @@ extern "C" int gct_attn_mask_pack(const uint8_t* mask, int64_t mask_sb, int64_t 
   hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask,
                      mask_sb, mask_sq, B, rows, Lk, bits);
   GCT_LAUNCH_CHECK("attn_mask_pack");
+  if (tiles) {          // [B][1] for a key-padding mask, [B][ceil(Lq / 16)] otherwise
+    const int ntr = mask_sq == 0 ? 1 : (Lq + 15) / 16;
+    const int64_t items = (int64_t)B * ntr;
+    hipLaunchKernelGGL(mask_tiles_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, bits,
+                       rows * MASK_W, mask_sq == 0 ? 0 : MASK_W, B, ntr, Lq, Lk, tiles);
+    GCT_LAUNCH_CHECK("attn_mask_pack (tiles)");
+  }
   return GCT_OK;
 }
 
@@ -1368,7 +1444,8 @@ extern "C" int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t
                             const float* v, int64_t ldv, const uint32_t* mbits, int64_t mb_sb,
                             int64_t mb_sq, float* o, int64_t ldo, float* lse, float* probs, int B,
                             int H, int Lq, int Lk, int dk, float scale, float p, uint64_t seed,
-                            uint32_t site, const int32_t* kstart, const int32_t* klen, void* stream) {
+                            uint32_t site, const int32_t* kstart, const int32_t* klen, const uint32_t* tbits,
+                            int64_t tb_sb, int64_t tb_su, void* stream) {
   int rc = check_common("attn_fwd", q, ldq, k, ldk, v, ldv, mbits, mb_sb, mb_sq, B, H, Lq, Lk, dk, p);
   if (rc) return rc;
   GCT_CHECK_ARG(o && lse && ldo % 4 == 0 && gct_aligned16(o) && (int64_t)Lq * ldo * 4 < (1ll << 31), "attn_fwd: bad output");
@@ -1377,6 +1454,10 @@ extern "C" int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t
   a.q = q; a.k = k; a.v = v; a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv;
   a.mbits = mbits; a.mb_sb = (int)mb_sb; a.mb_sq = (int)mb_sq;
   a.o = o; a.ldo = (int)ldo; a.lse = lse; a.probs = probs;
+  a.tbits = tbits; a.tb_sb = (int)tb_sb; a.tb_su = (int)tb_su;
+#ifdef GCT_STAMPS
+  a.stamps = g_attn_stamps;
+#endif
   GCT_CHECK_ARG((kstart == nullptr) == (klen == nullptr), "attn_fwd: kstart / klen go together");
   a.kstart = kstart; a.klen = klen;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.npairs = B * H; a.scale = scale;
@@ -1408,7 +1489,8 @@ extern "C" int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t
                             int64_t lddk, float* dv, int64_t lddv, int B, int H, int Lq, int Lk,
                             int dk, float scale, float p, uint64_t seed, uint32_t site,
                             const int32_t* cstart, const int32_t* nlive, int kv_compact,
-                            const int32_t* kstart, const int32_t* klen, void* ws, int64_t ws_bytes, void* stream) {
+                            const int32_t* kstart, const int32_t* klen, const uint32_t* tbits, int64_t tb_sb,
+                            int64_t tb_su, void* ws, int64_t ws_bytes, void* stream) {
   int rc = check_common("attn_bwd", q, ldq, k, ldk, v, ldv, mbits, mb_sb, mb_sq, B, H, Lq, Lk, dk, p);
   if (rc) return rc;
   GCT_CHECK_ARG(o && dout && lse && dq && dk_ && dv, "attn_bwd: null pointer");
@@ -1423,7 +1505,11 @@ extern "C" int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t
   a.q = q; a.k = k; a.v = v; a.ldq = (int)ldq; a.ldk = (int)ldk; a.ldv = (int)ldv;
   a.mbits = mbits; a.mb_sb = (int)mb_sb; a.mb_sq = (int)mb_sq;
   a.o_in = o; a.dout = dout; a.ldo = (int)ldo; a.lse_in = lse;
+  a.tbits = tbits; a.tb_sb = (int)tb_sb; a.tb_su = (int)tb_su;
   a.dq = dq; a.dk = dk_; a.dv = dv; a.lddq = (int)lddq; a.lddk = (int)lddk; a.lddv = (int)lddv;
+#ifdef GCT_STAMPS
+  a.stamps = g_attn_stamps;
+#endif
   GCT_CHECK_ARG((cstart == nullptr) == (nlive == nullptr) && (!kv_compact || (cstart && Lq == Lk)),
                 "attn_bwd: cstart / nlive go together; kv_compact needs them and Lq == Lk");
   a.cstart = cstart; a.nlive = nlive; a.kv_compact = kv_compact;

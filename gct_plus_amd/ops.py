@@ -470,7 +470,12 @@ class MaskBits:
         self.u8, self.B, self.Lq, self.Lk = mask_u8, B, Lq, Lk
         self.bits = torch.empty(B, rows, 8, dtype=torch.int32, device=mask_u8.device)
         self.sb, self.sq = rows * 8, (0 if sq == 0 else 8)
-        check(_L().gct_attn_mask_pack(_p(mask_u8), sb, sq, B, Lq, Lk, _p(self.bits), _st()), "gct_attn_mask_pack")
+        # visible key tiles per (batch, query tile): lets the kernels request K before the mask rows are back
+        ntr = 1 if sq == 0 else (Lq + 15) // 16
+        self.tiles = torch.empty(B, ntr, dtype=torch.int32, device=mask_u8.device)
+        self.t_sb, self.t_su = ntr, (0 if sq == 0 else 1)
+        check(_L().gct_attn_mask_pack(_p(mask_u8), sb, sq, B, Lq, Lk, _p(self.bits), _p(self.tiles), _st()),
+              "gct_attn_mask_pack")
 
 
 def pack_mask(mask, B, Lq, Lk) -> Optional["MaskBits"]:
@@ -486,7 +491,16 @@ def _mb(mask, B, Lq, Lk):
     """(pointer, batch stride, row stride, owner): the caller keeps `owner` referenced until its launch is enqueued --
     a mask packed on the fly lives only in that object, and a freed block may be handed to the next torch.empty."""
     mb = pack_mask(mask, B, Lq, Lk)
-    return (None, 0, 0, None) if mb is None else (mb.bits.data_ptr(), mb.sb, mb.sq, mb)
+    if mb is None:
+        return None, 0, 0, None
+    if mb.t_su and mb.Lq != Lq:
+        raise _lib.GctError(f"packed mask was built for Lq={mb.Lq}, not Lq={Lq}")
+    return mb.bits.data_ptr(), mb.sb, mb.sq, mb
+
+
+def _tb(mb):
+    """(tile words, batch stride, query-tile stride) of a packed mask."""
+    return (None, 0, 0) if mb is None else (mb.tiles.data_ptr(), mb.t_sb, mb.t_su)
 
 
 def attn_fwd(q, k, v, ld_q, ld_k, ld_v, mask, B, H, Lq, Lk, dk, p, seed, site, out=None,
@@ -501,7 +515,7 @@ def attn_fwd(q, k, v, ld_q, ld_k, ld_v, mask, B, H, Lq, Lk, dk, p, seed, site, o
     check(_L().gct_attn_fwd(_p(q), ld_q, _p(k), ld_k, _p(v), ld_v, mp, sb, sq, _p(o),
                             o.stride(0), _p(lse), _p(probs), B, H, Lq, Lk, dk,
                             1.0 / math.sqrt(dk), p, seed, site, None if keys is None else _p(keys.cstart),
-                            None if keys is None else _p(keys.n_b), _st()), "gct_attn_fwd")
+                            None if keys is None else _p(keys.n_b), *_tb(mask_owner), _st()), "gct_attn_fwd")
     del mask_owner
     return o, lse, probs
 
@@ -532,7 +546,8 @@ def attn_bwd(q, k, v, ld_q, ld_k, ld_v, mask, o, dout, lse, dq, dk_, dv, ld_dq, 
                             _p(dv), ld_dv, B, H, Lq, Lk, dk, 1.0 / math.sqrt(dk), p, seed, site,
                             None if live is None else _p(live.cstart), None if live is None else _p(live.n_b),
                             int(bool(kv_compact)), None if keys is None else _p(keys.cstart),
-                            None if keys is None else _p(keys.n_b), _p(ws), 0 if ws is None else ws.numel(),
+                            None if keys is None else _p(keys.n_b), *_tb(mask_owner), _p(ws),
+                            0 if ws is None else ws.numel(),
                             _st()), "gct_attn_bwd")
     del mask_owner
 

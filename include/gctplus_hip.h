@@ -37,7 +37,7 @@ extern "C" {
 #define GCT_ERR_ARG (-1)  /* bad shape / alignment / null pointer            */
 #define GCT_ERR_HIP (-2)  /* a HIP runtime call failed (launch error)        */
 
-#define GCT_ABI_VERSION 5
+#define GCT_ABI_VERSION 6
 
 int gct_version(void);
 const char* gct_last_error(void);
@@ -237,13 +237,17 @@ int gct_dropout_bwd(const float* dout, float* dy, int64_t rows, int cols, float 
  * dk in {16, 32, 64}; Lq, Lk <= 256 (the reference's positional table ends at 200: Model/modules.py:117). */
 /* mask: uint8, element (b,q,k) at mask[b*mask_sb + q*mask_sq + k] (0 = masked); mask_sq == 0: key-padding mask
  * [B][Lk] -> bits [B][8]; else bits [B][Lq][8]. */
+/* tiles (nullable): one word per (batch, 16-row query tile) -- [B][1] for a key-padding mask, [B][ceil(Lq/16)]
+ * otherwise -- bit t set <=> key tile t must be visited; passed to gct_attn_fwd / gct_attn_bwd as tbits with the
+ * strides (tb_sb, tb_su) = (1, 0) resp. (ceil(Lq/16), 1), it lets a wave request its K rows before its mask rows
+ * are back.  The kernels compute the same word themselves when tbits is NULL. */
 int gct_attn_mask_pack(const uint8_t* mask, int64_t mask_sb, int64_t mask_sq, int B, int Lq, int Lk,
-                       uint32_t* bits, void* stream);
+                       uint32_t* bits, uint32_t* tiles, void* stream);
 int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
                  int64_t ldv, const uint32_t* mbits, int64_t mb_sb, int64_t mb_sq,
                  float* o, int64_t ldo, float* lse, float* probs, int B, int H, int Lq, int Lk,
                  int dk, float scale, float p, uint64_t seed, uint32_t site, const int32_t* kstart,
-                 const int32_t* klen, void* stream);
+                 const int32_t* klen, const uint32_t* tbits, int64_t tb_sb, int64_t tb_su, void* stream);
 /* kstart / klen (nullable, together; gct_key_rows): k and v hold only the VISIBLE keys of every sample, quad-compacted:
  * the rows of sample b start at kstart[b] and there are klen[b] of them (keys klen[b]..Lk-1 are masked by mbits). */
 /* dq/dk/dv written (overwrite) with the same layout as q/k/v.
@@ -256,7 +260,8 @@ int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const
                  float* dq, int64_t lddq, float* dk_, int64_t lddk, float* dv, int64_t lddv,
                  int B, int H, int Lq, int Lk, int dk, float scale, float p, uint64_t seed,
                  uint32_t site, const int32_t* cstart, const int32_t* nlive, int kv_compact,
-                 const int32_t* kstart, const int32_t* klen, void* ws, int64_t ws_bytes, void* stream);
+                 const int32_t* kstart, const int32_t* klen, const uint32_t* tbits, int64_t tb_sb, int64_t tb_su,
+                 void* ws, int64_t ws_bytes, void* stream);
 /* kstart / klen as in gct_attn_fwd: k, v AND dk, dv hold the visible keys only (excludes kv_compact).
  * ws (nullable, caller-owned, 16-B aligned, >= gct_attn_bwd_ws_bytes): scratch of the two-launch backward used for
  * Lk <= 96 (one wave per query tile -> dq, then one wave per key tile -> dk, dv; no LDS); without it, or beyond 96
