@@ -21,7 +21,7 @@ SIGNATURES = {
     "gct_rowred_ws_bytes": (I64, [I64, I64]),
     "gct_embed_ws_bytes": (I64, [I32, I32, I32, I32]),
     "gct_norm_fwd": (I32, [P, P, P, P, P, P, I64, I32, F32, P]),
-    "gct_norm_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, I64, I32, F32, P, I64, P]),
+    "gct_norm_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, I64, I32, F32, P, I64, P, F32, U64, U32, P]),
     "gct_embed_pe_fwd": (I32, [P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, U64, U32, P]),
     "gct_embed_pe_bwd": (I32, [P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, U64, U32, P]),
     "gct_linear_fwd": (I32, [P, I64, I64, I32, P, P, P, I64, P, P, P, I32, I32, P, P, P, I64,

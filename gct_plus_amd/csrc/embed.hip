@@ -60,22 +60,45 @@ __global__ __launch_bounds__(256) void embed_pe_bwd_kernel(const float* __restri
   const int64_t g0 = (int64_t)blockIdx.y * groups_per_chunk;
   const int64_t g1 = g0 + groups_per_chunk < ngroups ? g0 + groups_per_chunk : ngroups;
   if (col < d) {
+    // the gradient rows and token ids of group gq + 1 are requested before group gq is accumulated (the LDS
+    // read-modify-write chain of a group hides behind the next group's HBM latency; without this the loop ran one
+    // dependent load after the other: 140 us for 85 MB)
+    float cur[4], nxt[4] = {0.f, 0.f, 0.f, 0.f};
+    int64_t ctok[4], ntok[4] = {0, 0, 0, 0};
+    auto fetch = [&](int64_t gq, float (&v)[4], int64_t (&t)[4]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t row = gq * 4 + e;
+        const int64_t rr = row < rows ? row : rows - 1;
+        v[e] = dout[rr * d + col];
+        const int b = (int)(rr / L), l = (int)(rr - (int64_t)b * L);
+        t[e] = l < n_c ? 0 : tok[(int64_t)b * S + (l - n_c)];
+      }
+    };
+    if (g0 < g1) fetch(g0, cur, ctok);
     for (int64_t gq = g0; gq < g1; ++gq) {
+      if (gq + 1 < g1) fetch(gq + 1, nxt, ntok);
       uint4 bits = make_uint4(~0u, ~0u, ~0u, ~0u);
       if (thr) bits = gct_drop_bits(rng, (uint32_t)gq, (uint32_t)col);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int64_t row = gq * 4 + e;
-        if (row >= rows) break;
-        const float g = gct_drop_keep(bits, e, (uint32_t)col, thr) ? dout[row * d + col] * gscale : 0.f;
-        const int b = (int)(row / L), l = (int)(row - (int64_t)b * L);
-        if (l < n_c) {
-          dcond[((int64_t)b * n_c + l) * d + col] = g;
-        } else {
-          int64_t t = tok[(int64_t)b * S + (l - n_c)];
-          t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
-          acc[t * 256 + tx] += g;
+        if (row < rows) {
+          const float g = gct_drop_keep(bits, e, (uint32_t)col, thr) ? cur[e] * gscale : 0.f;
+          const int b = (int)(row / L), l = (int)(row - (int64_t)b * L);
+          if (l < n_c) {
+            dcond[((int64_t)b * n_c + l) * d + col] = g;
+          } else {
+            int64_t t = ctok[e];
+            t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+            acc[t * 256 + tx] += g;
+          }
         }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        cur[e] = nxt[e];
+        ctok[e] = ntok[e];
       }
     }
     float* p = partial + (int64_t)blockIdx.y * vocab * d;
@@ -84,8 +107,8 @@ __global__ __launch_bounds__(256) void embed_pe_bwd_kernel(const float* __restri
 }
 
 inline int embed_chunks(int64_t rows) {
-  int64_t c = (rows / 4 + 63) / 64;
-  if (c > 256) c = 256;
+  int64_t c = (rows / 4 + 15) / 16;      // >= 16 groups of 4 rows per chunk; 2 x 512 workgroups at B x S = 41k rows
+  if (c > 512) c = 512;
   if (c < 1) c = 1;
   return (int)c;
 }

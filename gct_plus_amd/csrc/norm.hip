@@ -84,7 +84,10 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ dres, float* dx,
                                                        float* partial, int64_t rows, int d,
                                                        float eps, const int32_t* __restrict__ qmap,
-                                                       int64_t src_rows) {
+                                                       int64_t src_rows, float* dropo, uint32_t thr, float dscale,
+                                                       GctRng rng) {
+  // dropo (nullable): a second output, dropout_bwd(dx) with the mask of the dropout the PRECEDING sub-layer applied
+  // to its output (the next consumer of this gradient) -- saves that sub-layer's separate dropout_bwd pass
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   float4 a[NC], pa[NC], pb[NC];
@@ -96,7 +99,23 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
     pa[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     pb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += nwaves) {
+  // a wave takes whole QUADS of rows: the dropout bits of the second output cover 4 rows x 2 columns per Philox call,
+  // so one set of calls serves the four rows of a quad
+  const int64_t nquads = (rows + 3) >> 2;
+  for (int64_t quad = (int64_t)blockIdx.x * 4 + wave; quad < nquads; quad += nwaves) {
+   uint4 db[NC][2];
+   if (dropo) {
+     const int64_t oq = qmap ? (int64_t)qmap[quad] : quad;
+#pragma unroll
+     for (int c = 0; c < NC; ++c) {
+       const int col = c * 256 + lane * 4;
+       db[c][0] = gct_drop_bits(rng, (uint32_t)(oq < 0 ? 0 : oq), (uint32_t)col);
+       db[c][1] = gct_drop_bits(rng, (uint32_t)(oq < 0 ? 0 : oq), (uint32_t)col + 2);
+     }
+   }
+   for (int e4 = 0; e4 < 4; ++e4) {
+    const int64_t row = quad * 4 + e4;
+    if (row >= rows) break;
     // qmap: dy / dres / dx are quad-compacted (csrc/liverows.hip); x, mean, rstd stay in the forward's row space
     int64_t srow = row;
     if (qmap) {
@@ -107,7 +126,10 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           const int col = c * 256 + lane * 4;
-          if (col < d) *reinterpret_cast<float4*>(dr0 + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (col < d) {
+            *reinterpret_cast<float4*>(dr0 + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (dropo) *reinterpret_cast<float4*>(dropo + row * d + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
         }
         continue;
       }
@@ -154,8 +176,20 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
           o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
         }
         *reinterpret_cast<float4*>(dr + col) = o;
+        if (dropo) {
+          // mask coordinates are the forward's (row, col); row & 3 == e4 in both row spaces (quads are aligned)
+          const int e = e4;
+          const uint4 b0 = db[c][0], b1 = db[c][1];
+          float4 m;
+          m.x = gct_drop_keep(b0, e, (uint32_t)col, thr) ? o.x * dscale : 0.f;
+          m.y = gct_drop_keep(b0, e, (uint32_t)col + 1, thr) ? o.y * dscale : 0.f;
+          m.z = gct_drop_keep(b1, e, (uint32_t)col + 2, thr) ? o.z * dscale : 0.f;
+          m.w = gct_drop_keep(b1, e, (uint32_t)col + 3, thr) ? o.w * dscale : 0.f;
+          *reinterpret_cast<float4*>(dropo + row * d + col) = m;
+        }
       }
     }
+   }
   }
   // combine the 4 waves' column partials through LDS, chunk by chunk (fixed order)
   __shared__ float4 comb[4][64];
@@ -217,9 +251,11 @@ extern "C" int gct_norm_fwd(const float* x, const float* alpha, const float* bia
 extern "C" int gct_norm_bwd(const float* dy, const float* x, const float* alpha, const float* mean,
                             const float* rstd, const float* dres, float* dx, float* dalpha,
                             float* dbias, float* ws, int64_t rows, int d, float eps,
-                            const int32_t* quad_map, int64_t src_rows, void* stream) {
+                            const int32_t* quad_map, int64_t src_rows, float* drop_out, float p, uint64_t seed,
+                            uint32_t site, void* stream) {
   GCT_CHECK_ARG(dy && x && alpha && mean && rstd && dx && dalpha && dbias && ws,
                 "norm_bwd: null pointer");
+  GCT_CHECK_ARG(!drop_out || (gct_aligned16(drop_out) && p >= 0.f && p < 1.f), "norm_bwd: bad dropout output");
   GCT_CHECK_ARG(!quad_map || (rows % 4 == 0 && src_rows > 0), "norm_bwd: compacted rows come in quads");
   GCT_CHECK_ARG(rows >= 0 && d >= 4 && d % 4 == 0 && d <= 256 * MAXC, "norm_bwd: d=%d unsupported", d);
   GCT_CHECK_ARG(gct_aligned16(dy) && gct_aligned16(x) && gct_aligned16(dx) && gct_aligned16(alpha) &&
@@ -228,7 +264,8 @@ extern "C" int gct_norm_bwd(const float* dy, const float* x, const float* alpha,
   hipStream_t st = (hipStream_t)stream;
   const int nblk = norm_blocks(rows);
   dim3 grid((unsigned)nblk);
-  NORM_DISPATCH(norm_bwd_kernel, dy, x, alpha, mean, rstd, dres, dx, ws, rows, d, eps, quad_map, src_rows);
+  NORM_DISPATCH(norm_bwd_kernel, dy, x, alpha, mean, rstd, dres, dx, ws, rows, d, eps, quad_map, src_rows, drop_out,
+                gct_drop_threshold(p), 1.0f / (1.0f - p), gct_rng_make(seed, site));
   GCT_LAUNCH_CHECK("norm_bwd");
   // partial layout [blk][2][d]: one slab per block, destinations dalpha | dbias
   return gct_reduce_slabs_seg(ws, nblk, (int64_t)2 * d, dalpha, dbias, nullptr, d, (int64_t)2 * d, st);

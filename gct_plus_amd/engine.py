@@ -133,8 +133,9 @@ def mha_fwd(run: Run, m, xq, xkv, B, Lq, Lk, mask_u8, resid, want_probs=False, k
 
 
 def mha_bwd(run: Run, m, saved, dy, G: GradSink, dxq_out, depi_q, dxkv_out=None,
-            depi_kv=ops.DEPI_STORE, live=None):
-    """dy: gradient w.r.t. the block output (resid + dropout(out(o)) or out(o)).
+            depi_kv=ops.DEPI_STORE, live=None, gdrop=None):
+    """dy: gradient w.r.t. the block output (resid + dropout(out(o)) or out(o)); gdrop: dropout_bwd(dy) already
+    computed by the producer of dy (ops.norm_bwd(drop=...)).
     Writes dW/db through G, d(xq) into dxq_out (epilogue depi_q) and, for cross-attention,
     d(xkv) into dxkv_out (epilogue depi_kv).  The identity path to `resid` is the caller's.
     live (ops.LiveRows): the QUERY-side rows (dy, dxq_out) are quad-compacted; saved forward tensors are
@@ -152,7 +153,10 @@ def mha_bwd(run: Run, m, saved, dy, G: GradSink, dxq_out, depi_q, dxkv_out=None,
         o_in, xq_in = live.gather(o), live.gather(xq)
     else:
         o_in, xq_in = o, xq
-    g = ops.dropout_bwd(dy, run.p, run.seed, site_o, live=live) if (fused and run.p > 0) else dy
+    if gdrop is not None:
+        g = gdrop
+    else:
+        g = ops.dropout_bwd(dy, run.p, run.seed, site_o, live=live) if (fused and run.p > 0) else dy
     ops.linear_wgrad([g], d, o_in, [G(m.out.weight)], [G(m.out.bias)], kt=kt)
     do = _empty(Mq, d, dy) if live is None else live.empty(d)
     ops.linear_dgrad([g], d, Mq, [m.out.weight], do)
@@ -205,7 +209,7 @@ def ffn_fwd(run: Run, ff, x, resid):
     return y, (x, pre, hdn, site_h, site_o, resid is not None)
 
 
-def ffn_bwd(run: Run, ff, saved, dy, G: GradSink, dx_out, depi, live=None):
+def ffn_bwd(run: Run, ff, saved, dy, G: GradSink, dx_out, depi, live=None, gdrop=None):
     x, pre, hdn, site_h, site_o, fused = saved
     M, d = x.shape
     dff = pre.shape[1]
@@ -214,7 +218,10 @@ def ffn_bwd(run: Run, ff, saved, dy, G: GradSink, dx_out, depi, live=None):
         M, kt = live.Mc, None
         x, hdn = live.gather(x), live.gather(hdn)     # (pre stays in place: the GELU-backward epilogue reads it
                                                       #  through the quad map)
-    g = ops.dropout_bwd(dy, run.p, run.seed, site_o, live=live) if (fused and run.p > 0) else dy
+    if gdrop is not None:
+        g = gdrop
+    else:
+        g = ops.dropout_bwd(dy, run.p, run.seed, site_o, live=live) if (fused and run.p > 0) else dy
     ops.linear_wgrad([g], d, hdn, [G(ff.linear_2.weight)], [G(ff.linear_2.bias)], kt=kt)
     dpre = _empty(M, dff, dy) if live is None else live.empty(dff)
     ops.linear_dgrad([g], d, M, [ff.linear_2.weight], dpre, depi=ops.DEPI_GELU_BWD, pre=pre,
@@ -232,18 +239,33 @@ def enc_layer_fwd(run: Run, layer, x_in, B, L, mask_u8, want_probs=False):
     return out, (x_in, m1, r1, sv_a, a, m2, r2, sv_f), probs
 
 
-def enc_layer_bwd(run: Run, layer, saved, g, G: GradSink):
-    """g: mutable [M,d] gradient buffer w.r.t. the layer output; returns d(x_in) in g."""
+def _mha_drop(run: Run, sv, buf):
+    """ops.norm_bwd(drop=...) request for the attention block saved in sv: the Norm backward that produces the
+    gradient of that block's output also writes dropout_bwd of it (the block's own first step) into buf."""
+    return (buf, run.p, run.seed, sv[11]) if (buf is not None and sv[12] and run.p > 0) else None
+
+
+def _ffn_drop(run: Run, sv, buf):
+    return (buf, run.p, run.seed, sv[4]) if (buf is not None and sv is not None and sv[5] and run.p > 0) else None
+
+
+def enc_layer_bwd(run: Run, layer, saved, g, G: GradSink, gd=None, gdbuf=None, below=None):
+    """g: mutable [M,d] gradient buffer w.r.t. the layer output; returns d(x_in) in g.
+    gd: dropout_bwd(g) for this layer's FFN if the caller's Norm backward already produced it; gdbuf: scratch
+    [M,d] for the fused dropout_bwd outputs; below: saved FFN state of the layer underneath (its dropout_bwd is
+    written by this layer's last Norm backward) -- returns (g, that buffer or None)."""
     x_in, m1, r1, sv_a, a, m2, r2, sv_f = saved
     # out = n2 + drop(ffn(n2))  =>  d(n2) = g + ffn'(g): the W1 dgrad accumulates into g
-    ffn_bwd(run, layer.ff, sv_f, g, G, g, ops.DEPI_ACCUM)
+    ffn_bwd(run, layer.ff, sv_f, g, G, g, ops.DEPI_ACCUM, gdrop=gd)
+    dr = _mha_drop(run, sv_a, gdbuf)
     ops.norm_bwd(g, a, layer.norm_2.alpha, m2, r2, G(layer.norm_2.alpha), G(layer.norm_2.bias),
-                 out=g, eps=layer.norm_2.eps)
+                 out=g, eps=layer.norm_2.eps, drop=dr)
     # a = n1 + drop(attn(n1))
-    mha_bwd(run, layer.attn, sv_a, g, G, g, ops.DEPI_ACCUM)
+    mha_bwd(run, layer.attn, sv_a, g, G, g, ops.DEPI_ACCUM, gdrop=None if dr is None else gdbuf)
+    dr = _ffn_drop(run, below, gdbuf)
     ops.norm_bwd(g, x_in, layer.norm_1.alpha, m1, r1, G(layer.norm_1.alpha), G(layer.norm_1.bias),
-                 out=g, eps=layer.norm_1.eps)
-    return g
+                 out=g, eps=layer.norm_1.eps, drop=dr)
+    return g, (None if dr is None else gdbuf)
 
 
 def dec_layer_fwd(run: Run, layer, x, e, B, T, Lk, src_mask_u8, trg_mask_u8, want_probs=False, keys=None):
@@ -256,21 +278,25 @@ def dec_layer_fwd(run: Run, layer, x, e, B, T, Lk, src_mask_u8, trg_mask_u8, wan
     return xc, (x, m1, r1, sv1, xa, m2, r2, sv2, xb, m3, r3, svf), p1, p2
 
 
-def dec_layer_bwd(run: Run, layer, saved, g, de, first_de, G: GradSink, live=None):
-    """live (ops.LiveRows): g and every row-wise gradient of this layer are quad-compacted [live.Mc, d]."""
+def dec_layer_bwd(run: Run, layer, saved, g, de, first_de, G: GradSink, live=None, gd=None, gdbuf=None, below=None):
+    """live (ops.LiveRows): g and every row-wise gradient of this layer are quad-compacted [live.Mc, d].
+    gd / gdbuf / below as in enc_layer_bwd; returns (g, dropout_bwd(g) for the FFN of the layer underneath or None)."""
     x, m1, r1, sv1, xa, m2, r2, sv2, xb, m3, r3, svf = saved
     t = torch.empty_like(g) if live is None else live.empty(g.shape[1])
-    ffn_bwd(run, layer.ff, svf, g, G, t, ops.DEPI_STORE, live=live)
+    ffn_bwd(run, layer.ff, svf, g, G, t, ops.DEPI_STORE, live=live, gdrop=gd)
+    dr = _mha_drop(run, sv2, gdbuf)
     ops.norm_bwd(t, xb, layer.norm_3.alpha, m3, r3, G(layer.norm_3.alpha), G(layer.norm_3.bias),
-                 dres=g, out=g, eps=layer.norm_3.eps, live=live)
+                 dres=g, out=g, eps=layer.norm_3.eps, live=live, drop=dr)
     mha_bwd(run, layer.attn_2, sv2, g, G, t, ops.DEPI_STORE, de,
-            ops.DEPI_STORE if first_de else ops.DEPI_ACCUM, live=live)
+            ops.DEPI_STORE if first_de else ops.DEPI_ACCUM, live=live, gdrop=None if dr is None else gdbuf)
+    dr = _mha_drop(run, sv1, gdbuf)
     ops.norm_bwd(t, xa, layer.norm_2.alpha, m2, r2, G(layer.norm_2.alpha), G(layer.norm_2.bias),
-                 dres=g, out=g, eps=layer.norm_2.eps, live=live)
-    mha_bwd(run, layer.attn_1, sv1, g, G, t, ops.DEPI_STORE, live=live)
+                 dres=g, out=g, eps=layer.norm_2.eps, live=live, drop=dr)
+    mha_bwd(run, layer.attn_1, sv1, g, G, t, ops.DEPI_STORE, live=live, gdrop=None if dr is None else gdbuf)
+    dr = _ffn_drop(run, below, gdbuf)
     ops.norm_bwd(t, x, layer.norm_1.alpha, m1, r1, G(layer.norm_1.alpha), G(layer.norm_1.bias),
-                 dres=g, out=g, eps=layer.norm_1.eps, live=live)
-    return g
+                 dres=g, out=g, eps=layer.norm_1.eps, live=live, drop=dr)
+    return g, (None if dr is None else gdbuf)
 
 
 # ---------------------------------------------------------------------------------- trunks
@@ -309,10 +335,15 @@ def encoder_trunk_bwd(enc, run: Run, saved, dy, G: GradSink):
     src, econds, site_pe, lsv, x_last, mean, rstd, B, L = saved
     d, nc = enc.d_model, enc.nconds
     g = dy.reshape(B * L, d).clone()
+    # every Norm backward also writes dropout_bwd of its result for the sub-layer that consumes it next (gdbuf)
+    gdbuf = torch.empty_like(g) if (run.p > 0 and len(lsv) > 0) else None
+    dr = _ffn_drop(run, lsv[-1][-1] if lsv else None, gdbuf)
     ops.norm_bwd(g, x_last, enc.norm.alpha, mean, rstd, G(enc.norm.alpha), G(enc.norm.bias), out=g,
-                 eps=enc.norm.eps)
-    for layer, sv in zip(reversed(enc.layers), reversed(lsv)):
-        g = enc_layer_bwd(run, layer, sv, g, G)
+                 eps=enc.norm.eps, drop=dr)
+    gd = None if dr is None else gdbuf
+    for i in range(len(lsv) - 1, -1, -1):
+        g, gd = enc_layer_bwd(run, enc.layers[i], lsv[i], g, G, gd=gd, gdbuf=gdbuf,
+                              below=lsv[i - 1][-1] if i > 0 else None)
     dcond = torch.empty(B, nc * d, dtype=torch.float32, device=g.device) if nc > 0 else None
     ops.embed_pe_bwd(g, src, G(enc.embed_sentence.embed.weight), dcond, nc, math.sqrt(d), run.p,
                      run.seed, site_pe)
@@ -398,24 +429,28 @@ def decoder_trunk_bwd(dec, run: Run, saved, dy, G: GradSink, need_dz=True):
             live = lr
     if live is not None:
         gc = live.gather(g)
+        gdbuf = live.empty(d) if run.p > 0 else None
+        dr = _ffn_drop(run, lsv[-1][-1], gdbuf)
         ops.norm_bwd(gc, x_last, dec.norm.alpha, mean, rstd, G(dec.norm.alpha), G(dec.norm.bias), out=gc,
-                     eps=dec.norm.eps, live=live)
+                     eps=dec.norm.eps, live=live, drop=dr)
+        gd = None if dr is None else gdbuf
         de = new_de()
-        first = True
-        for layer, sv in zip(reversed(dec.layers), reversed(lsv)):
-            gc = dec_layer_bwd(run, layer, sv, gc, de, first, G, live=live)
-            first = False
+        for i in range(len(lsv) - 1, -1, -1):
+            gc, gd = dec_layer_bwd(run, dec.layers[i], lsv[i], gc, de, i == len(lsv) - 1, G, live=live, gd=gd,
+                                   gdbuf=gdbuf, below=lsv[i - 1][-1] if i > 0 else None)
         g = live.scatter(gc)                            # back to [B*T, d]: zero rows where nothing was live
     else:
         g = g.clone()
         run.kt = lr.kt if (lr is not None and (B * T) % 32 == 0) else None
+        gdbuf = torch.empty_like(g) if (run.p > 0 and len(lsv) > 0) else None
+        dr = _ffn_drop(run, lsv[-1][-1] if lsv else None, gdbuf)
         ops.norm_bwd(g, x_last, dec.norm.alpha, mean, rstd, G(dec.norm.alpha), G(dec.norm.bias), out=g,
-                     eps=dec.norm.eps)
+                     eps=dec.norm.eps, drop=dr)
+        gd = None if dr is None else gdbuf
         de = new_de()
-        first = True
-        for layer, sv in zip(reversed(dec.layers), reversed(lsv)):
-            g = dec_layer_bwd(run, layer, sv, g, de, first, G)
-            first = False
+        for i in range(len(lsv) - 1, -1, -1):
+            g, gd = dec_layer_bwd(run, dec.layers[i], lsv[i], g, de, i == len(lsv) - 1, G, gd=gd, gdbuf=gdbuf,
+                                  below=lsv[i - 1][-1] if i > 0 else None)
         run.kt = None
     if len(dec.layers) == 0:
         de.zero_()
@@ -749,7 +784,7 @@ class EncLayerFn(torch.autograd.Function):
     def backward(ctx, dy, *unused):
         B, L, d = ctx.shp
         G = GradSink()
-        g = enc_layer_bwd(ctx.run, ctx.layer, ctx.saved, _f32c(dy).reshape(B * L, d).clone(), G)
+        g, _ = enc_layer_bwd(ctx.run, ctx.layer, ctx.saved, _f32c(dy).reshape(B * L, d).clone(), G)
         ctx.saved = None
         return (None, None, g.view(B, L, d), None, None) + G.collect(ctx.params)
 
@@ -773,8 +808,8 @@ class DecLayerFn(torch.autograd.Function):
         B, T, Lk, d = ctx.shp
         G = GradSink()
         de = torch.empty(B * Lk, d, dtype=torch.float32, device=dy.device)
-        g = dec_layer_bwd(ctx.run, ctx.layer, ctx.saved, _f32c(dy).reshape(B * T, d).clone(), de,
-                          True, G)
+        g, _ = dec_layer_bwd(ctx.run, ctx.layer, ctx.saved, _f32c(dy).reshape(B * T, d).clone(), de,
+                             True, G)
         ctx.saved = None
         return (None, None, g.view(B, T, d), de.view(B, Lk, d), None, None, None) + \
             G.collect(ctx.params)

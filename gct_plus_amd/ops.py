@@ -112,9 +112,10 @@ def norm_fwd(x2d, alpha, bias, eps=1e-6, out=None):
     return y, mean, rstd
 
 
-def norm_bwd(dy, x2d, alpha, mean, rstd, dalpha, dbias, dres=None, out=None, eps=1e-6, live=None):
+def norm_bwd(dy, x2d, alpha, mean, rstd, dalpha, dbias, dres=None, out=None, eps=1e-6, live=None, drop=None):
     """live (LiveRows): dy / dres / out are quad-compacted rows [live.Mc, d]; x2d, mean, rstd stay in the forward's
-    row space."""
+    row space.  drop = (buffer, p, seed, site): also write dropout_bwd(result) with that mask into buffer (the
+    gradient's next consumer is the sub-layer whose output dropout used (seed, site))."""
     src_rows, d = x2d.shape
     rows = src_rows if live is None else live.Mc
     dx = (torch.empty_like(x2d) if live is None else live.empty(d)) if out is None else out
@@ -122,7 +123,9 @@ def norm_bwd(dy, x2d, alpha, mean, rstd, dalpha, dbias, dres=None, out=None, eps
     ws = workspace(_L().gct_rowred_ws_bytes(rows, 2 * d), x2d.device)
     check(_L().gct_norm_bwd(_p(dy), _p(x2d), _p(alpha), _p(mean), _p(rstd), _p(dres), _p(dx),
                             _p(dalpha), _p(dbias), _p(ws), rows, d, eps,
-                            None if live is None else _p(live.quad_list), src_rows, _st()), "gct_norm_bwd")
+                            None if live is None else _p(live.quad_list), src_rows,
+                            None if drop is None else _p(drop[0]), 0.0 if drop is None else drop[1],
+                            0 if drop is None else drop[2], 0 if drop is None else drop[3], _st()), "gct_norm_bwd")
     return dx
 
 

@@ -57,7 +57,9 @@ int gct_norm_fwd(const float* x, const float* alpha, const float* bias, float* y
 int gct_norm_bwd(const float* dy, const float* x, const float* alpha, const float* mean,
                  const float* rstd, const float* dres, float* dx, float* dalpha, float* dbias,
                  float* ws, int64_t rows, int d, float eps, const int32_t* quad_map, int64_t src_rows,
-                 void* stream);
+                 float* drop_out, float p, uint64_t seed, uint32_t site, void* stream);
+/* drop_out (nullable, same rows as dx): additionally dropout_bwd(dx) with the mask (seed, site, p) of the dropout the
+ * preceding sub-layer applied to its output -- that sub-layer's backward reads it instead of running gct_dropout_bwd. */
 
 /* --------------------------------------------------- K1: embedding + PE (+cond) */
 /* Model/modules.py:108-110 (lookup), :134-144 (x*sqrt(d)+pe, dropout),
