@@ -962,6 +962,139 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const GemmArgs g) {
 }
 
 
+// =====================================================================================
+// PANEL kernel for the smallest skinny problems (a 512-row decode step: M x N / (32 x TN) <= ~512 tiles): one
+// workgroup per 32 x TN output tile runs the WHOLE reduction -- no split-K slabs, no fix-up launch -- on K chunks of
+// 256: the chunk's operand panels (A 32 x 256, B TN x 256 fp32) are requested in one burst (8 + TN/4 float4 per
+// thread in flight), written to LDS once and multiplied from there (v_mfma_f32_16x16x4_f32, four waves = 2 x 2 or
+// 2 x 4 sub-tiles); the next chunk's burst is in flight during the MFMAs.  A step of the KV-cached decode is ~37
+// dependent GEMMs, each far too small to fill the chip: what counts is the latency of one launch (was: 64 x 64
+// tiles with K split 4-12 ways, 17 us, + a 9 us fix-up launch).
+// =====================================================================================
+template <int TN>
+__global__ __launch_bounds__(256) void gemm_f32_panel_kernel(const GemmArgs g) {
+  constexpr int TM = 32, KC = 256, SD = KC + 4, NBL = TN / 4;   // NBL float4 of the B panel per thread and chunk
+  extern __shared__ __attribute__((aligned(16))) float plds[];
+  float* As = plds;                    // [TM][SD]
+  float* Bs = plds + TM * SD;          // [TN][SD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, c16 = lane & 15;
+  const unsigned tiles_m = (unsigned)((g.M + TM - 1) / TM);
+  const unsigned lid = gct_xcd_remap(blockIdx.x, gridDim.x);
+  // consecutive logical ids (= one XCD) share a weight panel
+  const int64_t m0 = (int64_t)(lid % tiles_m) * TM, n0 = (int64_t)(lid / tiles_m) * TN;
+  const bool s1 = n0 >= g.b_nper, s2 = n0 >= 2 * g.b_nper;     // the TN weight rows lie in one segment
+  const float* bbase = g.b.p0 + (s2 ? g.b.d2 : (s1 ? g.b.d1 : 0)) + (n0 - (s2 ? 2 * g.b_nper : (s1 ? g.b_nper : 0))) * g.ldb;
+  const float* abase = g.a.p0;
+  uint32_t offa[8], offb[NBL];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = tid + 256 * i, row = idx >> 6, c4 = idx & 63;
+    int64_t r = m0 + row;
+    if (r > g.M - 1) r = g.M - 1;
+    offa[i] = (uint32_t)(r * g.lda + c4 * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NBL; ++i) {
+    const int idx = tid + 256 * i, row = idx >> 6, c4 = idx & 63;
+    offb[i] = (uint32_t)(row * g.ldb + c4 * 4);
+  }
+  f32x4_t ra[8], rb[NBL];           // native vectors: HIP's float4 struct copies kept these arrays in scratch
+  auto gload = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ra[i] = *reinterpret_cast<const f32x4_t*>(abase + k0 + offa[i]);
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) rb[i] = *reinterpret_cast<const f32x4_t*>(bbase + k0 + offb[i]);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i;
+      *reinterpret_cast<f32x4_t*>(As + (idx >> 6) * SD + (idx & 63) * 4) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+      const int idx = tid + 256 * i;
+      *reinterpret_cast<f32x4_t*>(Bs + (idx >> 6) * SD + (idx & 63) * 4) = rb[i];
+    }
+  };
+  constexpr int NS = TN / 32;          // 16 x 16 sub-tiles per wave (they share the A fragment)
+  const int wm = (wave >> 1) * 16, wn = (wave & 1) * (TN / 2);
+  f32x4_t acc[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int64_t nch = g.K / KC;
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int64_t c = 0; c < nch; ++c) {
+    if (c + 1 < nch) gload((c + 1) * KC);
+    // lane group g4 owns k = 64 g4 .. 64 g4 + 63 of the chunk for BOTH operands (any k permutation is legal)
+    const float* ap = As + (wm + c16) * SD + g4 * 64;
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const float4 a4 = *reinterpret_cast<const float4*>(ap + 4 * j);
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        const float4 b4 = *reinterpret_cast<const float4*>(Bs + (wn + 16 * u + c16) * SD + g4 * 64 + 4 * j);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[u], 0, 0, 0);
+      }
+    }
+    __syncthreads();                   // every wave is done with this chunk's panels
+    if (c + 1 < nch) {
+      lstore();
+      __syncthreads();
+    }
+  }
+  // epilogue: per-wave 16 x 16 transpose through LDS (the panels are free), one 4 x 4 patch per lane 0..15
+  float* stg = plds + wave * (16 * 20);
+  const FastEpi ep{g};
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stg[(4 * g4 + i) * 20 + c16] = acc[u][i];   // C[m = 4 g4 + i][n = c16]
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 16) {
+      const int pr = lane >> 2, pc = lane & 3;
+      const int64_t row0 = m0 + wm + 4 * pr, col0 = n0 + wn + 16 * u + 4 * pc;
+      if (row0 < g.M && col0 < g.N) {
+        float4 v[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) v[rr] = *reinterpret_cast<const float4*>(stg + (4 * pr + rr) * 20 + 4 * pc);
+        const bool q1 = col0 >= g.c_nper, q2 = col0 >= 2 * g.c_nper;
+        const int64_t cloc = col0 - (q2 ? 2 * g.c_nper : (q1 ? g.c_nper : 0));
+        float* cbase = g.c0 + (q2 ? g.c_d2 : (q1 ? g.c_d1 : 0));
+        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias0) bias = *reinterpret_cast<const float4*>(g.bias0 + (q2 ? g.bias_d2 : (q1 ? g.bias_d1 : 0)) + cloc);
+        ep.apply(v, row0, col0, cbase, cloc, bias);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int TN>
+int launch_panel(const GemmArgs& g, hipStream_t st) {
+  constexpr size_t LDS = (size_t)(32 + TN) * 260 * sizeof(float);
+  static bool attr_set = false;        // per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_panel_kernel<TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    if (e != hipSuccess) {
+      gct_set_error("gemm_f32_panel: cannot reserve %zu bytes of LDS: %s", LDS, hipGetErrorString(e));
+      return GCT_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  const int64_t tiles = ((g.M + 31) / 32) * (g.N / TN);
+  hipLaunchKernelGGL((gemm_f32_panel_kernel<TN>), dim3((unsigned)tiles), dim3(256), LDS, st, g);
+  GCT_LAUNCH_CHECK("gemm_f32_panel");
+  return GCT_OK;
+}
+
 // split-K tail of the skinny-M path: out = epilogue(sum_s slab[s] + bias ...), one 4x4 patch per
 // thread, float4 everywhere, same FastEpi as the GEMM kernels.
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs g, const float* slabs,
@@ -1141,6 +1274,15 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
   // skinny M (decode steps): 64x64 tiles when the 128x128 grid would leave most CUs idle
   if (fast && A_KC && B_KC && g.nsplit == 1 && tiles < 192 && g.epi < EPI_D0 &&
       (g.b_nper >= g.N || g.b_nper % 64 == 0)) {
+    // ... and the panel kernel (whole reduction in one workgroup, one launch) when even those are few
+    static const bool no_panel = getenv("GCT_GEMM_NO_PANEL") != nullptr;   // A/B switch for benchmarks
+    if (!no_panel && g.K % 256 == 0 && g.lda * 4 * 33 < (1ll << 31) && g.ldb * 4 * 65 < (1ll << 31) &&
+        (g.c_nper >= g.N || g.c_nper % 64 == 0)) {
+      const int64_t tm32 = (g.M + 31) / 32;
+      if (g.N % 32 == 0 && (g.b_nper >= g.N || g.b_nper % 32 == 0) && tm32 * (g.N / 32) <= 384)
+        return launch_panel<32>(g, st);
+      if (g.N % 64 == 0 && tm32 * (g.N / 64) <= 768) return launch_panel<64>(g, st);
+    }
     const int64_t st_ = ((g.M + 63) / 64) * ((g.N + 63) / 64);
     const int64_t nkt = g.K / BK;
     int64_t ns = 1;

@@ -585,6 +585,37 @@ def test_linear_bf16x6_epilogues_and_dropout_masks(ops, M, N):
         close(c[i], a[i].double(), 5e-5, 1e-4, what)
 
 
+@pytest.mark.parametrize("M,K,nper,nseg", [(512, 512, 512, 1), (512, 512, 512, 3), (512, 512, 2048, 1),
+                                           (512, 2048, 512, 1), (77, 512, 64, 1), (300, 768, 128, 2)])
+def test_linear_panel_kernel_small_problems(ops, M, K, nper, nseg):
+    """The decode-step shapes (few 32 x TN tiles, K a multiple of 256) take gemm_f32_panel_kernel: whole reduction in
+    one workgroup, fused epilogue, no split-K slabs.  Values vs fp64 for the plain, GELU(+pre) and residual
+    epilogues; the same launches with GCT's other skinny route (split-K + fix-up, forced through splitk_ws) agree to
+    fp32 rounding."""
+    N = nper * nseg
+    x = rnd(M, K, seed=1)
+    ws = [rnd(nper, K, seed=10 + s, scale=K ** -0.5) for s in range(nseg)]
+    bs = [rnd(nper, seed=20 + s) for s in range(nseg)]
+    r = rnd(M, N, seed=4)
+    xg, rg = x.to(DEV), r.to(DEV)
+    wg, bg = [w.to(DEV) for w in ws], [b.to(DEV) for b in bs]
+    u = x.double() @ torch.cat(ws).double().t() + torch.cat(bs).double()
+    y, pre, y2 = (torch.empty(M, N, device=DEV) for _ in range(3))
+    outs = lambda t: [t[:, s * nper:] for s in range(nseg)]                     # noqa: E731
+    ops.linear_fwd(xg, wg, bg, outs(y), N)
+    close(y, u, 2e-5, 2e-5, "panel: bias")
+    if nseg == 1:
+        ops.linear_fwd(xg, wg, bg, [y], N, epi=ops.EPI_GELU_DROP, pre=pre, p=0.0, seed=1, site=1)
+        close(pre, u, 2e-5, 2e-5, "panel: pre")
+        close(y, torch.nn.functional.gelu(u), 2e-5, 2e-5, "panel: gelu")
+        ops.linear_fwd(xg, wg, bg, [y2], N, epi=ops.EPI_DROP_RESID, resid=rg, p=0.0, seed=1, site=2)
+        close(y2, u + r.double(), 2e-5, 2e-5, "panel: residual")
+        wsb = torch.empty(int(ops._L().gct_linear_fwd_ws_bytes(M, K, N)) // 4 + 64, device=DEV)
+        y3 = torch.empty(M, N, device=DEV)
+        ops.linear_fwd(xg, wg, bg, [y3], N, epi=ops.EPI_DROP_RESID, resid=rg, p=0.0, seed=1, site=2, splitk_ws=wsb)
+        close(y3, y2.double(), 2e-5, 2e-5, "panel vs split-K route")
+
+
 def test_linear_bf16x6_split_k_over_the_whole_problem(ops):
     """Few 128x256 tiles and a long reduction (FFN-2 of a decode step with >= 1 024 rows): with a workspace the bf16x6
     kernel runs with K split into slabs + the fix-up kernel (which applies the fused epilogue).  Same dropout mask and
