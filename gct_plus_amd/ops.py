@@ -120,6 +120,8 @@ def norm_bwd(dy, x2d, alpha, mean, rstd, dalpha, dbias, dres=None, out=None, eps
     rows = src_rows if live is None else live.Mc
     dx = (torch.empty_like(x2d) if live is None else live.empty(d)) if out is None else out
     _wait_pending(out)
+    if drop is not None:
+        _wait_pending(drop[0])
     ws = workspace(_L().gct_rowred_ws_bytes(rows, 2 * d), x2d.device)
     check(_L().gct_norm_bwd(_p(dy), _p(x2d), _p(alpha), _p(mean), _p(rstd), _p(dres), _p(dx),
                             _p(dalpha), _p(dbias), _p(ws), rows, d, eps,
