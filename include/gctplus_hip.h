@@ -236,7 +236,8 @@ int gct_dropout_bwd(const float* dout, float* dy, int64_t rows, int cols, float 
  * Pack once per forward: the same rows serve every layer, every head and the backward pass.
  * o: [B][Lq][H*dk] (heads merged, ready for the out projection); lse: [B][H][Lq].
  * probs (nullable): pre-dropout probabilities [B][H][Lq][Lk] (get_attn path).
- * dk in {16, 32, 64}; Lq, Lk <= 256 (the reference's positional table ends at 200: Model/modules.py:117). */
+ * dk in {16, 32, 64}; Lq, Lk <= 208 (the reference's positional table ends at 200: Model/modules.py:117; + 3
+ * condition tokens).  Lk <= 96 runs the barrier-free kernels (one wave per query / key tile), longer rows the LDS kernels. */
 /* mask: uint8, element (b,q,k) at mask[b*mask_sb + q*mask_sq + k] (0 = masked); mask_sq == 0: key-padding mask
  * [B][Lk] -> bits [B][8]; else bits [B][Lq][8]. */
 /* tiles (nullable): one word per (batch, 16-row query tile) -- [B][1] for a key-padding mask, [B][ceil(Lq/16)]
