@@ -512,8 +512,12 @@ __device__ __forceinline__ void tile_load(typename VecN<NDT>::T (&v)[4], const c
   }
 }
 
+#ifndef GCT_FWD_NH          // A/B knobs: -DGCT_FWD_NH=2 -DGCT_FWD_OCC=5, -DGCT_FWD_NH=3 -DGCT_FWD_OCC=4
+#define GCT_FWD_NH 1
+#define GCT_FWD_OCC 6
+#endif
 template <int NDT, int NT>
-__global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, GCT_FWD_OCC) void attn_fwd_direct_kernel(const AttnArgs a) {
   constexpr int DK = 16 * NDT, MW = (NT + 1) / 2;
   typedef typename VecN<NDT>::T VT;
   const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
@@ -527,9 +531,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs 
   const int Lk_in = a.klen ? a.klen[b] : a.Lk;            // keys that exist as rows; the others are masked keys
   const int64_t kr0 = a.kstart ? (int64_t)a.kstart[b] : (int64_t)b * a.Lk;
   const int klast = Lk_in > 0 ? Lk_in - 1 : 0;
-  __shared__ __attribute__((aligned(16))) float tiles[4][2][16 * WaveTile<NDT>::SD];
+  // one LDS tile per wave (17 KB per workgroup): K tile t+1 is written after tile t's fragment has been read -- the
+  // wave's LDS instructions execute in order
+  __shared__ __attribute__((aligned(16))) float tiles[4][16 * WaveTile<NDT>::SD];
   const int wv = threadIdx.x >> 6;
-  const WaveTile<NDT> T0{tiles[wv][0]}, T1{tiles[wv][1]};
+  const WaveTile<NDT> T0{tiles[wv]}, T1{tiles[wv]};
   // Q rows of this tile and the K rows of the visible key tiles arrive coalesced and become row-per-lane fragments in
   // the wave's LDS tiles (WaveTile); rows beyond the existing keys re-read the last one: their scores are masked
   VT tq[4];
@@ -540,10 +546,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs 
   VT tk[NT][4];
   // with the precomputed tile word (a scalar load) the K requests go out before the mask rows are back
   uint32_t use = 0;
+  // K / V tiles are requested in batches of NH that reuse one set of registers.  NH = 1: 71 VGPRs, 6-7 waves per SIMD;
+  // NH = 2: 87 VGPRs / 5 waves, +1-3 %; NH = 3: 103 / 4, +5 %; all six tiles at once: 150 VGPRs / 3 waves, +12 % --
+  // what hides the L2 latency here is the other waves, not the depth of one wave's request queue
+  constexpr int NH = GCT_FWD_NH;
   if (a.tbits) {
     use = __builtin_amdgcn_readfirstlane(a.tbits[(int64_t)b * a.tb_sb + u * a.tb_su]);
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NH; ++t)
       if ((use >> t) & 1u) tile_load<NDT>(tk[t], kbase, a.ldk, 16 * t, klast, g, c16);
   }
   uint32_t mw[MW];
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs 
   if (!a.tbits) {
     use = tiles_for_q<MW>(mw, q, a.Lq, a.Lk, nkt);
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NH; ++t)
       if ((use >> t) & 1u) tile_load<NDT>(tk[t], kbase, a.ldk, 16 * t, klast, g, c16);
   }
   ASTAMP(0);                           // Q / mask / K requests, mask arrival (visible tiles when not precomputed)
@@ -566,7 +576,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs 
 #pragma unroll
   for (int t = 0; t < NT; ++t) sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT; ++t) {
+    if (t >= NH && t % NH == 0) {      // next batch of K tiles, into the registers the previous one has left
+#pragma unroll
+      for (int t2 = t; t2 < t + NH && t2 < NT; ++t2)
+        if ((use >> t2) & 1u) tile_load<NDT>(tk[t2], kbase, a.ldk, 16 * t2, klast, g, c16);
+    }
     if ((use >> t) & 1u) {
       float4 ak[NDT];
       if (t & 1) {                     // alternate: tile t+1 is written while tile t is read
@@ -578,21 +593,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs 
       }
       sacc[t] = dot_frag<NDT>(ak, bq, sacc[t]);
     }
+  }
   ASTAMP(2);                           // K arrival -> LDS -> fragments, S^T issued
   // V fragments, requested now and consumed after the softmax: lane (c16, g) holds V[16t + 4g + r][NDT c16 .. + NDT)
   // -- output tile dt of the P.V product covers the head columns {NDT m + dt}
   const char* vbase = reinterpret_cast<const char*>(a.v + kr0 * a.ldv + h * DK);                  // wave-uniform
   VT av[NT][4];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-    if ((use >> t) & 1u) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kk = 16 * t + 4 * g + r;
-        const int rr = kk < klast ? kk : klast;
-        av[t][r] = *reinterpret_cast<const VT*>(vbase + (uint32_t)((rr * a.ldv + NDT * c16) * 4));
-      }
-    }
+  for (int t = 0; t < NH; ++t)
+    if ((use >> t) & 1u) tile_load<NDT>(av[t], vbase, a.ldv, 16 * t, klast, g, c16);
   ASTAMP(3);                           // V requests
   // scale + mask + softmax (as fwd_unit)
   float m = -INFINITY;
@@ -653,7 +662,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs 
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT; ++t) {
+    if (t >= NH && t % NH == 0) {      // next batch of V tiles
+#pragma unroll
+      for (int t2 = t; t2 < t + NH && t2 < NT; ++t2)
+        if ((use >> t2) & 1u) tile_load<NDT>(av[t2], vbase, a.ldv, 16 * t2, klast, g, c16);
+    }
     if ((use >> t) & 1u) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -661,6 +675,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_direct_kernel(const AttnArgs 
         for (int dt = 0; dt < NDT; ++dt) oacc[dt] = mfma16(vec_at<NDT>(av[t][r], dt), sacc[t][r], oacc[dt]);
       }
     }
+  }
   ASTAMP(5);                           // V arrival, P.V issued
   if (q < a.Lq) {
     char* obase = reinterpret_cast<char*>(a.o + (int64_t)b * a.Lq * a.ldo + h * DK);             // wave-uniform
