@@ -1158,7 +1158,7 @@ struct DkvBuf {                        // one query tile's operands of the dK / 
 };
 
 template <int NDT, int NT>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 4) void attn_bwd_dkv_kernel(const AttnArgs a) {
   constexpr int DK = 16 * NDT, MW = (NT + 1) / 2;
   const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
   const int nqt = (a.Lq + 15) >> 4, nkt = (a.Lk + 15) >> 4, LQP = 16 * nqt;
@@ -1250,13 +1250,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const AttnArgs a) 
     ASTAMP(1);                         // Q / dO tile + row scalar requests issued
     f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f}, pa = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
-      float4 aq[NDT], ad[NDT];           // the same rows as row-per-lane fragments, through the wave's LDS tiles
+      float4 aq[NDT];                    // the same rows as row-per-lane fragments, through the wave's LDS tiles
       T0.put(B_.tq, g, c16);
       T1.put(B_.td, g, c16);
       T0.get(aq, g, c16);
-      T1.get(ad, g, c16);
       sa = dot_frag<NDT>(aq, bk, sa);   // S[q][k] (unscaled)
-      pa = dot_frag<NDT>(ad, bv, pa);   // dP[q][k]
+      T1.get(aq, g, c16);
+      pa = dot_frag<NDT>(aq, bv, pa);   // dP[q][k]
     }
     ASTAMP(2);                         // Q / dO arrival -> LDS -> fragments, S / dP issued
     float pd[4], ds[4];
@@ -1272,14 +1272,23 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const AttnArgs a) 
       ds[r] = (inr && vis) ? p * (dpd - mt[r].y) : 0.f;
     }
     ASTAMP(3);                         // row scalars, S / dP results, P / dS arithmetic
+    // the coalesced rows again, as the A operands of dK^T / dV^T: re-read from the LDS tiles they were put into (32
+    // registers that would otherwise be held across the whole tile: 146 -> <= 128 VGPRs, four waves per SIMD)
+    typename VecN<NDT>::T tq2[4], td2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      tq2[r] = *reinterpret_cast<const typename VecN<NDT>::T*>(T0.t + (4 * g + r) * WaveTile<NDT>::SD + NDT * c16);
+      td2[r] = *reinterpret_cast<const typename VecN<NDT>::T*>(T1.t + (4 * g + r) * WaveTile<NDT>::SD + NDT * c16);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        vacc[dt] = mfma16(vec_at<NDT>(B_.td[r], dt), pd[r], vacc[dt]);   // dV^T[d][k] += dO[q][d] Pd[q][k]
-        kacc[dt] = mfma16(vec_at<NDT>(B_.tq[r], dt), ds[r], kacc[dt]);   // dK^T[d][k] += Q[q][d] dS[q][k]
+        vacc[dt] = mfma16(vec_at<NDT>(td2[r], dt), pd[r], vacc[dt]);   // dV^T[d][k] += dO[q][d] Pd[q][k]
+        kacc[dt] = mfma16(vec_at<NDT>(tq2[r], dt), ds[r], kacc[dt]);   // dK^T[d][k] += Q[q][d] dS[q][k]
       }
     }
+    __builtin_amdgcn_wave_barrier();   // the next tile's put must stay behind these reads
     ASTAMP(4);                         // dV / dK issued
   };
   while (rem) {                        // wave-uniform
