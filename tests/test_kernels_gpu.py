@@ -163,7 +163,8 @@ def ref_attention(q, k, v, mask, scale, keep=None, pkeep=1.0):
                                                (2, 8, 171, 171, 64, "causal"), (2, 8, 171, 173, 64, "pad"),
                                                (1, 4, 200, 200, 64, "causal"), (2, 2, 5, 208, 32, "none"),
                                                (2, 4, 203, 198, 16, "pad"), (2, 4, 40, 37, 16, "holes"),
-                                               (2, 8, 81, 81, 64, "holes")])
+                                               (2, 8, 81, 81, 64, "holes"), (2, 4, 150, 70, 64, "pad"),
+                                               (2, 4, 150, 70, 64, "causal"), (3, 2, 33, 96, 32, "holes")])
 def test_attention(ops, B, H, Lq, Lk, dk, mode):
     d = H * dk
     qkv = rnd(B * max(Lq, Lk), 3 * d, seed=1)
