@@ -4,34 +4,33 @@
 // folded into the addressing (q/k/v are read in place from the fused projection buffer, o is
 // written heads-merged).  The reference's positional table allows any L <= 200 (Model/modules.py:117).
 //
-// Machine mapping (gfx950).  One (batch, head) "pair" at a time lives in a workgroup's LDS: K and V
-// [L][dk+4] fp32.  All products run on v_mfma_f32_16x16x4_f32 (exact fp32).
+// Machine mapping (gfx950).  All products run on v_mfma_f32_16x16x4_f32 (exact fp32).
 //  * The score tile is computed TRANSPOSED (S^T = K Q^T): its accumulator layout has the key
 //    index on the registers and the query on the lane -- exactly the B-operand layout of the
 //    following P.V product (which sums over keys).  Probabilities never leave registers and
 //    never touch HBM; a softmax row is reduced over 4 regs x tiles in-lane plus two shuffles.
 //  * Masks arrive PACKED (gct_attn_mask_pack: one bit per key, 8 words per query row, packed once per
-//    forward and shared by all layers and heads).  A lane holds the words of its own query row in
-//    registers; visibility of a 16x16 tile, "row has a visible key" and the per-element mask bit are
-//    all bit operations on them -- no flag bytes in LDS (the previous kernel staged Lq x Lk of them).
+//    forward and shared by all layers and heads, plus one word of visible key tiles per 16-row query tile).
+//    A lane holds the words of its own query row in registers; visibility of a 16x16 tile, "row has a
+//    visible key" and the per-element mask bit are bit operations on them.
 //  * 16x16 score tiles without a visible (q,k) are skipped -- wave-uniform, and only when every query
 //    row of the tile has at least one visible key, so the masked_fill(-1e9) semantics (uniform row
-//    when everything is masked) stay exact.  Dropout keep bits: one Philox call per (query, 4 keys) in
+//    when everything is masked) stay exact.  Dropout keep bits: one Philox call per (query, 8 keys) in
 //    the lane that owns them, only for tiles that are computed.
-//  * Workgroups are PERSISTENT (grid = 2 per CU, 6 waves each) and software-pipelined over their pairs:
-//    the next pair's K, V (staging registers) and this wave's Q fragment are requested from HBM before
-//    the current pair's MFMAs start and are written to LDS after them, so HBM latency hides behind
-//    compute inside one workgroup instead of relying on co-resident workgroups drifting apart (the
-//    previous kernel's workgroups ran load -> compute in lockstep: 143 us for 336 MB).
-//  * Backward recomputes probabilities from the saved log-sum-exp (no [B,H,L,L] tensor) in two phases
-//    that REUSE one LDS region:
-//      phase A (K, V in LDS; one wave per query tile, Q / dO / O rows straight from HBM):
-//               S^T, dP^T -> dS^T -> dQ;   also delta = rowsum(dO * O), lse and "dO row is non-zero" -> LDS
-//      phase B (Q, dO in LDS -- their second read hits L2; one wave per key tile, K / V rows from L2):
-//               S, dP -> P_drop, dS -> dV, dK
-//    so every tensor crosses HBM once and a pair needs 2 x L x (dk+4) floats of LDS, not 4 x (L <= 256
-//    fits; 2-3 workgroups per CU at L = 80).  Query tiles whose dO rows are all zero are skipped in both.
-// Roofline: HBM-bound on q,k,v,o (+ gradients); 4.L.d flop/token ~ 3 % of the step's flops.
+//  * The backward recomputes probabilities from the saved log-sum-exp (no [B,H,L,L] tensor).
+// Two kernel families:
+//  * L_k <= 96 (every shipped configuration): BARRIER-FREE kernels, one wave per work item, no workgroup
+//    cooperation, a non-persistent grid the dispatcher balances: attn_fwd_direct_kernel (item = pair x query
+//    tile), attn_bwd_dq_kernel (pair x query tile -> dQ + per-row scalars / keep bits / visited tiles in a
+//    workspace), attn_bwd_dkv_kernel (pair x key tile -> dK, dV).  Operands reach a wave coalesced and are turned
+//    into the row-per-lane MFMA fragments in wave-private LDS tiles (WaveTile); a pair's K / V are re-read by its
+//    query tiles from L2, not HBM (measured HBM traffic = algorithmic bytes +1 %).  Register use is kept low on
+//    purpose (71 / 118 / 120 VGPRs): what hides the memory latency here is the number of resident waves.
+//  * 96 < L <= 208: the LDS kernels attn_fwd_kernel / attn_bwd_kernel -- one (batch, head) pair at a time in a
+//    persistent 6-wave workgroup's LDS (K and V [L][dk+4] fp32, software-pipelined over the pairs; the backward in
+//    two phases that reuse one LDS region).  GCT_ATTN_FWD_LDS=1 / GCT_ATTN_BWD_LDS=1 select them for any length.
+// Roofline: HBM-bound on q,k,v,o (+ gradients): 0.57 / 0.51 of it fwd / bwd at B=512;
+// 4.L.d flop/token ~ 3 % of the step's flops.
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
