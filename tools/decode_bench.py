@@ -17,6 +17,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=512)
 ap.add_argument("--model-type", default="vaetf")
 ap.add_argument("--ref-n", type=int, default=64, help="batch for the (slow) reference-style loop")
+ap.add_argument("--ragged", action="store_true", help="latent length 80 with MOSES-like valid lengths N(35,8) (padded "
+                "memory, as Inference/*_sampling.py batches it) instead of 40 fully valid positions")
 a = ap.parse_args()
 mtype = a.model_type
 vs, vt = synthetic.vocab_sizes(mtype)
@@ -24,10 +26,13 @@ nc = synthetic.n_conds(mtype)
 torch.manual_seed(1)
 model = model_dict[mtype](vs, vt, N=6, d_model=512, dff=2048, h=8, latent_dim=128, dropout=0.1, nconds=nc,
                           use_cond2lat=True).cuda().eval()
-n, Le = a.n, 40 + nc
+n, Le = a.n, (80 if a.ragged else 40) + nc
 z = torch.randn(n, Le, 128, device="cuda")
 dconds = torch.randn(n, nc, device="cuda") if nc else None
 src_mask = torch.ones(n, 1, Le, dtype=torch.bool, device="cuda")
+if a.ragged:
+    lens = (torch.randn(n, device="cuda") * 8 + 35).round().clamp(15, 80).long() + nc
+    src_mask = (torch.arange(Le, device="cuda")[None, :] < lens[:, None]).unsqueeze(1)
 ys0 = torch.full((n, 1), synthetic.SOS_ID, dtype=torch.long, device="cuda")
 kd = KVDecoder(model, synthetic.PAD_ID, synthetic.SOS_ID, eos_id=-1)       # never stop early: worst case
 for graphs in (False, True):
