@@ -19,13 +19,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
     int64_t kv_row, int64_t kv_batch, const uint8_t* __restrict__ valid, int64_t valid_sb,
     float* __restrict__ o, int64_t ldo, int n, int H, int Lc_host, float scale,
     const int32_t* __restrict__ pos, int cache_off, const float* __restrict__ knew,
-    const float* __restrict__ vnew, int64_t ldn) {
+    const float* __restrict__ vnew, int64_t ldn, const int32_t* __restrict__ klen) {
   __shared__ float sc[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
   if (pair >= (int64_t)n * H) return;
   const int b = (int)(pair / H), h = (int)(pair - (int64_t)b * H);
-  const int Lold = pos ? cache_off + *pos : Lc_host;          // keys already in the cache
+  // klen (nullable, without pos): the keys of sample b beyond klen[b] are masked (`valid` says so too) and b sees at
+  // least one key, so they weigh exactly 0: their cache rows are never read (the padded latent positions of the
+  // cross-attention memory are most of it at MOSES-like lengths)
+  const int Lold = pos ? cache_off + *pos : (klen ? klen[b] : Lc_host);          // keys already in the cache
   const int Lc = pos ? Lold + 1 : Lold;
   const float* qp = q + (int64_t)b * ldq + h * DK;
   float* kp = k + (int64_t)b * kv_batch + h * DK;
@@ -196,8 +199,9 @@ extern "C" int gct_attn_decode(const float* q, int64_t ldq, float* k, float* v,
                                int64_t kv_row, int64_t kv_batch, const uint8_t* valid,
                                int64_t valid_sb, float* o, int64_t ldo, int n, int H, int Lc, int dk,
                                float scale, const int32_t* pos, int cache_off, const float* knew,
-                               const float* vnew, int64_t ldn, void* stream) {
+                               const float* vnew, int64_t ldn, const int32_t* klen, void* stream) {
   GCT_CHECK_ARG(q && k && v && o && n >= 0 && H > 0 && Lc >= 0 && Lc <= 256, "attn_decode: bad args");
+  GCT_CHECK_ARG(!(klen && pos), "attn_decode: klen is for a fixed cache (cross-attention), not the device-position form");
   GCT_CHECK_ARG(pos || Lc > 0, "attn_decode: no keys");
   GCT_CHECK_ARG(!pos || (knew && vnew && ldn % 4 == 0 && gct_aligned16(knew) && gct_aligned16(vnew) && cache_off >= 0),
                 "attn_decode: the device-position form needs this step's key / value rows");
@@ -209,9 +213,9 @@ extern "C" int gct_attn_decode(const float* q, int64_t ldq, float* k, float* v,
   const int64_t pairs = (int64_t)n * H;
   dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (dk == 64) hipLaunchKernelGGL(attn_decode_kernel<64>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale, pos, cache_off, knew, vnew, ldn);
-  else if (dk == 32) hipLaunchKernelGGL(attn_decode_kernel<32>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale, pos, cache_off, knew, vnew, ldn);
-  else hipLaunchKernelGGL(attn_decode_kernel<16>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale, pos, cache_off, knew, vnew, ldn);
+  if (dk == 64) hipLaunchKernelGGL(attn_decode_kernel<64>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale, pos, cache_off, knew, vnew, ldn, klen);
+  else if (dk == 32) hipLaunchKernelGGL(attn_decode_kernel<32>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale, pos, cache_off, knew, vnew, ldn, klen);
+  else hipLaunchKernelGGL(attn_decode_kernel<16>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale, pos, cache_off, knew, vnew, ldn, klen);
   GCT_LAUNCH_CHECK("attn_decode");
   return GCT_OK;
 }

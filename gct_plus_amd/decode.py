@@ -84,6 +84,7 @@ class KVDecoder:
             self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
             self.ys = torch.full((n, T), self.pad_id, dtype=torch.int64, device=dev)
             self.src_valid = torch.empty(n, Lk, dtype=torch.uint8, device=dev)
+            self.src_klen = torch.empty(n, dtype=torch.int32, device=dev)  # leading memory rows the cross-attention reads
             self.pos = torch.zeros(1, dtype=torch.int32, device=dev)       # token index the next step consumes
             self.seed = torch.zeros(1, dtype=torch.int64, device=dev)      # multinomial seed of this generate()
             dff = dec.layers[0].ff.linear_1.weight.shape[0]
@@ -99,6 +100,11 @@ class KVDecoder:
                             xb=f(n, d), pre=f(n, dff), hdn=f(n, dff), xc=[f(n, d), f(n, d)], y=f(n, d),
                             logits=f(n, V))
         self.src_valid.copy_(sv)
+        # visible memory rows that form a non-empty prefix (the padding masks of Inference/*_sampling.py): the masked rows
+        # behind them weigh exactly 0, gct_attn_decode does not read them; any other mask keeps all Lk rows
+        cnt = sv.sum(1, dtype=torch.int32)
+        prefix = (sv[:, :-1] >= sv[:, 1:]).all(1) if Lk > 1 else torch.ones(n, dtype=torch.bool, device=dev)
+        self.src_klen.copy_(torch.where(prefix & (cnt > 0), cnt, torch.full_like(cnt, Lk)))
         for li, layer in enumerate(dec.layers):                    # cross K/V: once per sequence
             kv, a = self.cross_kv[li], layer.attn_2
             ops.linear_fwd(e, [a.k_linear.weight, a.v_linear.weight], [a.k_linear.bias, a.v_linear.bias],
@@ -162,7 +168,7 @@ class KVDecoder:
             ops.linear_fwd(B["x2"], [a2.q_linear.weight], [a2.q_linear.bias], [B["q2"]], d, **self.gemm_kw)
             kv = self.cross_kv[li]
             ops.attn_decode(B["q2"], d, kv, kv[:, d:], 2 * d, self.Lk * 2 * d, self.src_valid, self.Lk,
-                            B["o2"], n, self.H, self.Lk, self.dk)
+                            B["o2"], n, self.H, self.Lk, self.dk, klen=self.src_klen)
             ops.linear_fwd(B["o2"], [a2.out.weight], [a2.out.bias], [B["xb"]], d,
                            epi=ops.EPI_DROP_RESID, resid=B["xa"], **self.gemm_kw)
             ops.norm_fwd(B["xb"], layer.norm_3.alpha, layer.norm_3.bias, layer.norm_3.eps, out=B["x2"])

@@ -662,10 +662,11 @@ def add(a, b, out=None):
 
 # ----------------------------------------------------------------------------------- decode
 def attn_decode(q, ldq, k, v, kv_row, kv_batch, valid_u8, valid_sb, out, n, H, Lc, dk, pos=None, cache_off=0,
-                knew=None, vnew=None, ldn=0):
+                knew=None, vnew=None, ldn=0, klen=None):
+    """klen (int32 [n], optional, fixed caches only): leading keys to look at per sample (the rest are masked)."""
     check(_L().gct_attn_decode(_p(q), ldq, _p(k), _p(v), kv_row, kv_batch, _p(valid_u8), valid_sb,
                                _p(out), out.stride(0), n, H, Lc, dk, 1.0 / math.sqrt(dk), _p(pos), cache_off,
-                               _p(knew), _p(vnew), ldn, _st()), "gct_attn_decode")
+                               _p(knew), _p(vnew), ldn, _p(klen), _st()), "gct_attn_decode")
 
 
 def select_token(logits2d, ys, pos, valid_u8, done_u8, mode, pad_id, eos_id, seed=0, probs_out=None, pos_dev=None,

@@ -37,7 +37,7 @@ extern "C" {
 #define GCT_ERR_ARG (-1)  /* bad shape / alignment / null pointer            */
 #define GCT_ERR_HIP (-2)  /* a HIP runtime call failed (launch error)        */
 
-#define GCT_ABI_VERSION 6
+#define GCT_ABI_VERSION 7
 
 int gct_version(void);
 const char* gct_last_error(void);
@@ -315,11 +315,13 @@ int gct_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
  * pos (nullable) = DEVICE-side step counter: the caches hold cache_off + *pos keys, and this step's own key / value
  * (row b of knew / vnew, leading dimension ldn) are appended at that row and attended to -- one captured graph then
  * serves every step of the loop (gct_decode_embed / gct_select_token read the same counter, gct_decode_advance
- * increments it at the end of the step).  With pos == NULL the first Lc cached keys are used as they are. */
+ * increments it at the end of the step).  With pos == NULL the first Lc cached keys are used as they are.
+ * klen (nullable, only with pos == NULL): per-sample number of leading keys to look at -- for a key-padding mask
+ * whose visible keys are a non-empty prefix, the masked rows behind it weigh exactly 0 and are not read. */
 int gct_attn_decode(const float* q, int64_t ldq, float* k, float* v, int64_t kv_row,
                     int64_t kv_batch, const uint8_t* valid, int64_t valid_sb, float* o, int64_t ldo,
                     int n, int H, int Lc, int dk, float scale, const int32_t* pos, int cache_off,
-                    const float* knew, const float* vnew, int64_t ldn, void* stream);
+                    const float* knew, const float* vnew, int64_t ldn, const int32_t* klen, void* stream);
 /* x[b] = table[ys[b][*pos]] * scale + pe[pe_off + *pos] (Embeddings + PositionalEncoding of one position, eval mode) */
 int gct_decode_embed(const int64_t* ys, int64_t ld_ys, const int32_t* pos, int pe_off, const float* table,
                      int vocab, const float* pe, float* out, int n, int d, float scale, void* stream);

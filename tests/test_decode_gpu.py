@@ -203,3 +203,36 @@ def test_graph_replay_survives_restarts_with_other_shapes():
             assert outs[0].shape == outs[1].shape and torch.equal(outs[0], outs[1]), (call, algo)
         ngraphs.append(len(kd_g.graphs))
     assert ngraphs == [2, 2, 2, 2]          # one graph per selection mode, re-captured only when the geometry changed
+
+
+@pytest.mark.parametrize("mtype", ["vaetf", "pvaetf"])
+def test_kv_decode_source_masks_prefix_holes_and_empty(mtype):
+    """The cross-attention of a decode step reads only the leading visible memory rows when a sample's source mask is
+    a non-empty prefix (KVDecoder.src_klen); masks with holes, left-padded masks and a sample that sees NO memory row
+    (uniform attention over all of them) keep every row.  Token ids equal the un-cached reference-style loop."""
+    from gct_plus_amd.decode import KVDecoder, reference_style_decode
+    model = build(mtype, seed=5)
+    nc = synthetic.n_conds(mtype)
+    n, Le = 12, 24
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(n, Le, 16, generator=g).cuda()
+    dconds = torch.randn(n, nc, generator=g).cuda() if nc else None
+    lens = torch.randint(3, Le + 1, (n,), generator=g)
+    m = torch.arange(Le)[None, :] < lens[:, None]                       # prefixes
+    m[1] = torch.rand(Le, generator=g) < 0.5                             # holes
+    m[2] = torch.arange(Le) >= Le - 5                                    # left-padded
+    m[3] = False                                                         # sees nothing
+    m[4] = True                                                          # sees everything
+    src_mask = m.unsqueeze(1).cuda()
+    ys0 = torch.full((n, 1), synthetic.SOS_ID, dtype=torch.long, device="cuda")
+    ref = reference_style_decode(model, z, src_mask, dconds, ys0, synthetic.PAD_ID, -1, 20)
+    kd = KVDecoder(model, synthetic.PAD_ID, synthetic.SOS_ID, eos_id=-1)
+    kd.start(z, src_mask, dconds, max_total_len=32)
+    ys = kd.generate(ys0, max_strlen=20, use_graphs=True)
+    assert torch.equal(ys, ref)
+    klen = kd.src_klen.cpu()
+    Lk = Le + nc
+    assert int(klen[0]) == int(lens[0]) + nc and int(klen[1]) == Lk and int(klen[4]) == Lk
+    assert int(klen[3]) == (nc if nc else Lk)      # nothing visible: all rows (uniform); only the condition rows: those
+    # left-padded: with the condition rows in front (pvaetf) it is not a prefix either
+    assert int(klen[2]) == Lk
