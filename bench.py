@@ -236,18 +236,35 @@ def decode_block(model, a, dev, world, fence, reduce_max):
     src_mask = torch.ones(n, 1, Le, dtype=torch.bool, device=dev)
     ys0 = torch.full((n, 1), synthetic.SOS_ID, dtype=torch.long, device=dev)
     kd = KVDecoder(model, synthetic.PAD_ID, synthetic.SOS_ID, eos_id=-1)
-    kd.start(z, src_mask, dconds, max_total_len=96)
-    kd.generate(ys0, 80, use_graphs=True, check_every=0)          # warm-up + graph capture
+    # No collective sits inside the try: a rank that fails here still reaches the fence and the max-reduction below, so
+    # a decode problem on one rank can never hang the job or cost it the headline line.
+    err, dt_local, ys = None, 1e30, None                          # 1e30: "this rank failed" through the MAX reduction
+    try:
+        kd.start(z, src_mask, dconds, max_total_len=96)
+        kd.generate(ys0, 80, use_graphs=True, check_every=0)      # warm-up + graph capture
+        torch.cuda.synchronize()
+    except Exception as exc:                                      # noqa: BLE001
+        err = repr(exc)
     fence()
-    t0 = time.perf_counter()
-    kd.start(z, src_mask, dconds, max_total_len=96)               # prefill (cross K/V of all layers) is inside
-    ys = kd.generate(ys0, 80, use_graphs=True, check_every=0)
+    if err is None:
+        try:
+            t0 = time.perf_counter()
+            kd.start(z, src_mask, dconds, max_total_len=96)       # prefill (cross K/V of all layers) is inside
+            ys = kd.generate(ys0, 80, use_graphs=True, check_every=0)
+            torch.cuda.synchronize()
+            dt_local = time.perf_counter() - t0
+        except Exception as exc:                                  # noqa: BLE001
+            err = repr(exc)
     fence()
-    dt = reduce_max(time.perf_counter() - t0)
+    dt = reduce_max(dt_local)
     model.train(was_training)
+    if err is not None or dt > 1e20:
+        return {"metric": "decoded SMILES/sec (KV-cached greedy decode, max_strlen 80)", "value": None,
+                "error": err or "another rank failed"}
     return {"metric": "decoded SMILES/sec (KV-cached greedy decode, max_strlen 80)", "value": round(n * world / dt, 1),
             "unit": "SMILES/s", "n_per_gpu": n, "generated_tokens": int(ys.shape[1]) - 1, "latent_len": Le,
-            "ms_per_token": round(dt / 79 * 1e3, 3), "graph_replay": True, "model_type": a.model_type}
+            "ms_per_token": round(dt / 79 * 1e3, 3), "graph_replay": bool(getattr(kd, "graph_replay", True)),
+            "model_type": a.model_type}
 
 
 # ------------------------------------------------------------------------------------ worker

@@ -39,6 +39,7 @@ class KVDecoder:
         self.c2d = bool(dec.use_cond2dec and dec.nconds > 0)
         self.off = dec.nconds if self.c2d else 0          # cache / positional index of token 0
         self.graphs = {}
+        self.graph_replay = True
         self._shape = None
 
     # -------------------------------------------------------------------------------------
@@ -75,6 +76,7 @@ class KVDecoder:
             # new geometry: new buffers, and the graphs captured against the old ones are dropped with them
             # (they hold raw pointers: replaying them after a reallocation would write freed memory)
             self.graphs = {}
+            self.graph_replay = True
             self._shape = shape
             self.n, self.Lk, self.T = n, Lk, T
             self.cross_kv = [torch.empty(n * Lk, 2 * d, device=dev) for _ in dec.layers]
@@ -222,6 +224,10 @@ class KVDecoder:
             self._select(mode)
             return
         g = self.graphs.get(mode)
+        if g is False:                                  # capture failed earlier for these buffers: stay eager
+            self.step()
+            self._select(mode)
+            return
         if g is None:
             # Warm-up run on a side stream (lazy LDS opt-ins, allocator), then capture.  The warm-up really executes a
             # step (it advances the device position and writes a token), so the state it touches is restored before
@@ -236,9 +242,22 @@ class KVDecoder:
             # (the key / value row the warm-up appended is rewritten with the same values by the replay below)
             self.pos.copy_(keep[0]); self.ys.copy_(keep[1]); self.valid.copy_(keep[2]); self.done.copy_(keep[3])
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            try:
+                # thread_local: another thread's runtime calls (the RCCL watchdog of a data-parallel job queries
+                # events) must not invalidate this thread's capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.step()
+                    self._select(mode)
+            except RuntimeError as exc:                 # no graph for these buffers: same kernels, launched eagerly
+                import warnings
+                warnings.warn(f"KVDecoder: graph capture failed ({exc}); decoding without graph replay")
+                torch.cuda.synchronize()
+                self.pos.copy_(keep[0]); self.ys.copy_(keep[1]); self.valid.copy_(keep[2]); self.done.copy_(keep[3])
+                self.graphs[mode] = False
+                self.graph_replay = False
                 self.step()
                 self._select(mode)
+                return
             self.graphs[mode] = g
         g.replay()
 
