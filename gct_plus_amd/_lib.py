@@ -108,7 +108,16 @@ def load():
     return lib
 
 
+_TRACE = os.environ.get("GCT_TRACE_OPS", "0") != "0"    # debugging aid: name every launch on stderr and drain the device
+                                                        # after it, so that a faulting kernel is the last name printed
+
+
 def check(rc: int, what: str):
     if rc != 0:
         msg = load().gct_last_error().decode("utf-8", "replace")
         raise GctError(f"{what} failed (rc={rc}): {msg}")
+    if _TRACE:
+        import sys
+        import torch
+        print(f"[gct] {what}", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()

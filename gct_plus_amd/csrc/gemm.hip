@@ -1200,7 +1200,8 @@ int launch_x6_tail_split(const GemmArgs& g, hipStream_t st, float* ws, int64_t w
   e.c0 += m1 * g.ldc;
   if (e.resid) e.resid += m1 * g.ldc;
   if (e.pre) e.pre += m1 * g.ldc;
-  if (e.pre_in) e.pre_in += m1 * g.ldc;
+  // pre_in read through the quad map keeps the forward's row space: the tail finds its rows through row_base
+  if (e.pre_in && !(g.pre_rows > 0 && g.quad_map)) e.pre_in += m1 * g.ldc;
   GemmArgs p = e;
   p.nsplit = best;
   p.ksplit = ((nkt + best - 1) / best) * XBK;

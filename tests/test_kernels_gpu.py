@@ -647,6 +647,36 @@ def test_linear_bf16x6_split_k_over_the_whole_problem(ops):
     close(c, a.double(), 5e-5, 1e-4, "dropout + residual through the fix-up kernel")
 
 
+def test_dgrad_gelu_bwd_through_quad_map_with_tail_split(ops):
+    """GELU-backward dgrad on quad-compacted rows whose pre-activation stays in the forward's row space (read through the
+    quad map): at 33 row tiles x 8 column tiles the bf16x6 launch is tail-balanced (head + K-split tail + fix-up), and
+    the tail must find its pre-activation rows through row_base, not through a shifted pointer (a batch-128 training
+    step hit exactly this: out-of-bounds reads).  Reference: the same call on a gathered copy of the pre-activation."""
+    import types
+    Mfull, Mc, dff, d, p, seed = 8448, 4224, 2048, 512, 0.1, 11
+    g = torch.Generator().manual_seed(5)
+    quads = torch.randperm(Mfull // 4, generator=g)[:Mc // 4].sort().values.to(torch.int32)
+    live = types.SimpleNamespace(quad_list=quads.to(DEV), Mc=Mc)
+    pre = rnd(Mfull, dff, seed=1).to(DEV)
+    rows = (quads.long()[:, None] * 4 + torch.arange(4)[None, :]).reshape(-1).to(DEV)
+    pre_c = pre[rows].contiguous()
+    dy = rnd(Mc, d, seed=2).to(DEV)
+    w = rnd(d, dff, seed=3, scale=0.05)
+    flat, (wg,) = _planes_for(ops, [w])
+    try:
+        k0 = ops._L().gct_gemm_x6_kernel_launches()
+        a = torch.empty(Mc, dff, device=DEV)
+        ops.linear_dgrad([dy], d, Mc, [wg], a, depi=ops.DEPI_GELU_BWD, pre=pre, p=p, seed=seed, site=3, live=live,
+                         pre_full=True)
+        assert ops._L().gct_gemm_x6_kernel_launches() == k0 + 2          # head + K-split tail
+        b = torch.empty(Mc, dff, device=DEV)
+        ops.linear_dgrad([dy], d, Mc, [wg], b, depi=ops.DEPI_GELU_BWD, pre=pre_c, p=p, seed=seed, site=3, live=live,
+                         pre_full=False)
+    finally:
+        ops.unregister_planes(flat)
+    assert torch.equal(a, b)
+
+
 def test_wgrad_over_nonzero_row_tiles(ops):
     """gct_nonzero_row_tiles + gct_linear_wgrad_kt: reducing only over the 32-row token tiles whose gradient rows
     are not all zero gives the dense result (the skipped terms are exact zeros)."""
