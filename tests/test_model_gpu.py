@@ -192,6 +192,37 @@ def test_full_size_pscavaetf_large_batch_vs_oracle():
         assert_close(p.grad, e, 2e-5 * float(e.abs().max()) + floor, 1e-3, "grad " + name)
 
 
+def test_full_size_batch_128_vs_oracle():
+    """BASELINE dims, vaetf, B=128 (the reference scripts' batch size), MOSES-like lengths: the compacted decoder
+    backward has ~5 000 live rows, a tile count at which the GELU-backward dgrad (reading the pre-activation through the
+    quad map) is tail-balanced -- the combination that used to read out of bounds.  Loss and all gradients against the
+    CPU oracle."""
+    from oracle import gct_oracle as O
+    mtype, B = "vaetf", 128
+    model = build(mtype, full=True).train()
+    vs, vt = synthetic.vocab_sizes(mtype)
+    cfg = O.make_cfg(mtype, vs, vt, dropout=0.0, nconds=0, use_cond2lat=True)
+    P = O.make_leaves({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    ds = synthetic.make_dataset(B, max_len=80, model_type=mtype, seed=21)
+    eps = torch.randn(B, 80, 128, generator=torch.Generator().manual_seed(22))
+    set_eps(model, eps)
+    prop, mol, mu, lv, z, loss, rce, kld = run_fwd_loss(model, mtype, ds, 0.04)
+    sm, tm, trg_in = O.batch_masks(cfg, ds, PAD)
+    _, omol, omu, olv, oz = O.forward(P, cfg, ds["src"], trg_in, sm, tm, eps=eps, train=True)
+    assert_close(mol, omol, 1e-4, 1e-4, "logits")
+    ys = ds["trg"][:, 1:].contiguous().view(-1)
+    oloss, _, _, _ = O.loss_function(0.04, None, omol, None, ys, omu, olv, False, PAD)
+    assert abs(loss.item() - oloss.item()) <= 2e-5 * abs(oloss.item())
+    loss.backward()
+    oloss.backward()
+    floor = grad_floor(v.grad for v in P.values())
+    for name, p in model.named_parameters():
+        if P[name].grad is None:
+            continue
+        e = P[name].grad
+        assert_close(p.grad, e, 2e-5 * float(e.abs().max()) + floor, 1e-3, "grad " + name)
+
+
 def _args(mtype, d_model):
     nc = synthetic.n_conds(mtype)
     return SimpleNamespace(model_type=mtype, pad_id=PAD, use_cond2dec=False,

@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0)
 DROPOUT = 0.1
 
 
-def run(mtype, B, compact):
+def run(mtype, B, compact, S=80):
     engine.COMPACT_BWD = engine.COMPACT_KV = compact
     engine._SEED.update(base=None, ctr=0)          # same dropout / eps streams in both runs
     vs, vt = synthetic.vocab_sizes(mtype)
@@ -21,7 +21,7 @@ def run(mtype, B, compact):
     model = model_dict[mtype](vs, vt, dropout=DROPOUT, nconds=nc, use_cond2dec=False, use_cond2lat=True,
                               N=6, d_model=512, dff=2048, h=8, latent_dim=128).to(dev).train()
     opt = FusedAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-9, model=model)
-    ds = synthetic.make_dataset(B * 3, 80, mtype, seed=B, fixed_len=False)
+    ds = synthetic.make_dataset(B * 3, S, mtype, seed=B, fixed_len=False)
     losses = []
     torch.manual_seed(7)
     for batch in synthetic.batches(ds, B):
@@ -39,9 +39,9 @@ def run(mtype, B, compact):
 
 
 
-def compare(mtype, B):
+def compare(mtype, B, S=80):
     """max relative difference of the three per-sample losses, shortcuts on vs off"""
-    on, off = run(mtype, B, True), run(mtype, B, False)
+    on, off = run(mtype, B, True, S), run(mtype, B, False, S)
     assert all(x == x for x in on + off), (mtype, B, on, off)
     return max(abs(x - y) / max(abs(y), 1e-9) for x, y in zip(on, off)), on, off
 
@@ -51,15 +51,16 @@ if __name__ == "__main__":
     ap.add_argument("--batches", default="24,64,100,128,192,256,320,384,448,512")
     ap.add_argument("--model-types", default="vaetf,pscavaetf")
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--seqs", default="80", help="maximum SMILES lengths (source rows; the decoder sees one more)")
     a = ap.parse_args()
     DROPOUT = a.dropout
     bad = 0
     for mtype in a.model_types.split(","):
-        for B in [int(x) for x in a.batches.split(",")]:
-            rel, on, off = compare(mtype, B)
+        for B, S in [(int(x), int(y)) for x in a.batches.split(",") for y in a.seqs.split(",")]:
+            rel, on, off = compare(mtype, B, S)
             ok = rel < 2e-5
             bad += not ok
-            print(f"{mtype:10s} B={B:4d}  losses {['%.4f' % x for x in on]}  off {['%.4f' % x for x in off]}  max rel diff "
+            print(f"{mtype:10s} B={B:4d} S={S:3d}  losses {['%.4f' % x for x in on]}  off {['%.4f' % x for x in off]}  max rel diff "
                   f"{rel:.1e}  {'ok' if ok else 'MISMATCH'}", flush=True)
     print("sweep", "FAILED" if bad else "ok")
     sys.exit(1 if bad else 0)
