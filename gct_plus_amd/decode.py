@@ -20,12 +20,19 @@ passes to O(1).
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
 
 from . import engine, ops
 from ._lib import check
+
+
+# rows per step below which the step's GEMMs take the skinny fp32 kernels (panel / 64x64 split-K) instead of the general
+# path (bf16x6).  Measured on MI355X: n = 1100 / 1536 / 2048 / 3000 take 2.18 / 2.32 / 2.39 / 3.04 ms per token on the
+# general path against 2.27 / 2.46 / 2.58 / 3.74 on the skinny kernels; `GCT_DECODE_SKINNY_BELOW` overrides
+SKINNY_BELOW = int(os.environ.get("GCT_DECODE_SKINNY_BELOW", "1024"))
 
 
 class KVDecoder:
@@ -96,7 +103,7 @@ class KVDecoder:
                       ops._L().gct_linear_fwd_ws_bytes(n, d, V))
             self.ws = torch.empty(wsb // 4 + 64, device=dev)           # split-K / tail slabs of the step's GEMMs
             # few rows: the skinny split-K kernels; many rows (n >= 1024): the general path, i.e. the bf16x6 kernels
-            self.gemm_kw = dict(splitk_ws=self.ws) if n < 1024 else dict(ws=self.ws)
+            self.gemm_kw = dict(splitk_ws=self.ws) if n < SKINNY_BELOW else dict(ws=self.ws)
             f = lambda *sh: torch.empty(*sh, device=dev)                # noqa: E731
             self.buf = dict(x=f(n, d), x2=f(n, d), qkv=f(n, 3 * d), o=f(n, d), xa=f(n, d), q2=f(n, d), o2=f(n, d),
                             xb=f(n, d), pre=f(n, dff), hdn=f(n, dff), xc=[f(n, d), f(n, d)], y=f(n, d),
