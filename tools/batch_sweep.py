@@ -11,6 +11,7 @@ from gct_plus_amd.optim import FusedAdam
 dev = torch.device("cuda", 0)
 DROPOUT = 0.1
 FIXED_LEN = False
+DIMS = dict(N=6, d_model=512, dff=2048, h=8, latent_dim=128)
 
 
 def run(mtype, B, compact, S=80):
@@ -20,7 +21,7 @@ def run(mtype, B, compact, S=80):
     nc = synthetic.n_conds(mtype)
     torch.manual_seed(1)
     model = model_dict[mtype](vs, vt, dropout=DROPOUT, nconds=nc, use_cond2dec=False, use_cond2lat=True,
-                              N=6, d_model=512, dff=2048, h=8, latent_dim=128).to(dev).train()
+                              **DIMS).to(dev).train()
     opt = FusedAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-9, model=model)
     ds = synthetic.make_dataset(B * 3, S, mtype, seed=B, fixed_len=FIXED_LEN)
     losses = []
@@ -54,8 +55,12 @@ if __name__ == "__main__":
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--seqs", default="80", help="maximum SMILES lengths (source rows; the decoder sees one more)")
     ap.add_argument("--fixed-len", action="store_true", help="every sample at the maximum length (no padding)")
+    ap.add_argument("--dims", default="", help="N,d_model,h,dff,latent (default 6,512,8,2048,128)")
     a = ap.parse_args()
     DROPOUT, FIXED_LEN = a.dropout, a.fixed_len
+    if a.dims:
+        n_, d_, h_, f_, l_ = (int(x) for x in a.dims.split(","))
+        DIMS.update(N=n_, d_model=d_, h=h_, dff=f_, latent_dim=l_)
     bad = 0
     for mtype in a.model_types.split(","):
         for B, S in [(int(x), int(y)) for x in a.batches.split(",") for y in a.seqs.split(",")]:
