@@ -1,0 +1,109 @@
+"""Randomised sweep of the KV-cached decoder against the reference-style loop over the un-cached model.decode (same
+weights, same kernels for the un-cached forward): token ids must be equal.  Random model type, depth, width / heads,
+batch, memory length, source masks (full / prefix / holes), prefix lengths (scaffold-style), cond2dec, <eos> stop or
+fixed length, graph replay on / off.
+  python tools/decode_fuzz.py --cases 40 [--seed 1]
+A mismatch whose two candidate tokens are within 1e-5 in the un-cached logits is reported as a tie, not a failure
+(both loops take argmax of fp32 logits computed by different summation orders)."""
+import argparse, sys, torch
+sys.path.insert(0, ".")
+from gct_plus_amd import synthetic
+PAD, SOS, EOS = synthetic.PAD_ID, synthetic.SOS_ID, synthetic.EOS_ID
+
+
+def _uncached(model, z, src_mask, dconds, ys0, eos_id, max_strlen, c2d, nc):
+    from gct_plus_amd.Model.modules import get_trg_mask
+    ys = ys0.clone()
+    done = torch.zeros(ys.size(0), dtype=torch.bool, device=ys.device)
+    steps = []
+    for _ in range(max_strlen - 1):             # Sampling.decode appends max_strlen - 1 tokens to the prefix
+        tm = get_trg_mask(ys, PAD, c2d, dconds)
+        logits = model.decode(ys, z, src_mask, tm, dconds)
+        if c2d:
+            logits = logits[:, nc:]
+        last = logits[:, -1]
+        steps.append(last)
+        nxt = last.argmax(-1)
+        ys = torch.cat([ys, nxt[:, None]], dim=1)
+        done |= nxt == eos_id
+        if bool(done.all()):
+            break
+    return ys, steps
+
+
+def sweep(cases=30, seed=1, verbose=True):
+    from gct_plus_amd.Model import model_dict
+    from gct_plus_amd.decode import KVDecoder
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))          # noqa: E731
+    bad, ties = [], 0
+    for case in range(cases):
+        mtype = ["vaetf", "pvaetf", "scavaetf", "pscavaetf"][ri(0, 3)]
+        d_model, h = [(64, 4), (64, 2), (128, 8), (128, 2), (256, 4), (512, 8)][ri(0, 5)]
+        kw = dict(N=ri(1, 3), d_model=d_model, dff=[128, 256, 2048][ri(0, 2)], h=h, latent_dim=[16, 32, 128][ri(0, 2)])
+        nc = synthetic.n_conds(mtype)
+        c2d = bool(nc and ri(0, 2) == 0)
+        n = [ri(1, 9), ri(10, 70), ri(100, 600), 1024 + ri(0, 200)][min(ri(0, 4), 3)]
+        if d_model * n > 200000:
+            n = max(1, 200000 // d_model)
+        Le = ri(1, 60) + nc
+        npre = ri(0, 12) if mtype in ("scavaetf", "pscavaetf") else 0
+        max_strlen = 1 + ri(2, 40)
+        eos = EOS if ri(0, 1) else -1
+        graphs = bool(ri(0, 1))
+        vs, vt = synthetic.vocab_sizes(mtype)
+        torch.manual_seed(2000 + case)
+        model = model_dict[mtype](vs, vt, dropout=0.1, nconds=nc, use_cond2dec=c2d, use_cond2lat=not c2d if nc else True,
+                                  **kw).cuda().eval()
+        z = torch.randn(n, Le, kw["latent_dim"], generator=g).cuda()
+        dconds = torch.randn(n, nc, generator=g).cuda() if nc else None
+        mk = ri(0, 3)
+        if mk == 0:
+            sm = torch.ones(n, Le, dtype=torch.bool)
+        elif mk in (1, 2):
+            sm = torch.arange(Le)[None, :] < torch.randint(1, Le + 1, (n,), generator=g)[:, None]
+        else:
+            sm = torch.rand(n, Le, generator=g) < 0.7
+            sm[:, 0] = True
+        src_mask = sm.unsqueeze(1).cuda()
+        ys0 = torch.full((n, 1), SOS, dtype=torch.long)
+        if npre:
+            ys0 = torch.cat([ys0, torch.randint(5, vt, (n, npre), generator=g)], 1)
+        ys0 = ys0.cuda()
+        ref, steps = _uncached(model, z, src_mask, dconds, ys0, eos, max_strlen, c2d, nc)
+        kd = KVDecoder(model, PAD, SOS, eos)
+        kd.start(z, src_mask, dconds, max_total_len=1 + npre + max_strlen + 4)
+        out = kd.generate(ys0, max_strlen=max_strlen, use_graphs=graphs)
+        status = "equal"
+        if out.shape != ref.shape or not torch.equal(out, ref):
+            status = "MISMATCH"
+            if out.shape == ref.shape:
+                # first differing position of each differing sample: a tie in the un-cached logits?
+                diff = (out != ref)
+                first = diff.float().argmax(1)
+                rows = diff.any(1).nonzero().flatten()
+                tie = True
+                for r in rows.tolist():
+                    t = int(first[r]) - ys0.size(1)
+                    lg = steps[t][r]
+                    tie &= abs(float(lg[out[r, first[r]]] - lg[ref[r, first[r]]])) < 1e-5 * max(1.0, float(lg.abs().max()))
+                status = "tie" if tie else "MISMATCH"
+        ties += status == "tie"
+        line = (f"case {case:3d} {mtype:9s} N={kw['N']} d={d_model} h={h} dff={kw['dff']} n={n:4d} Le={Le:2d} prefix={npre:2d} "
+                f"len={max_strlen:2d} mask={mk} cond2dec={int(c2d)} eos={eos} graphs={int(graphs)} "
+                f"replayed={int(bool(getattr(kd, 'graph_replay', False)))} -> {status} {tuple(out.shape)}")
+        if verbose or status == "MISMATCH":
+            print(line, flush=True)
+        if status == "MISMATCH":
+            bad.append(line)
+        del model, kd
+    print(f"{cases} cases, ties: {ties}, failures: {len(bad)}", flush=True)
+    return bad
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=30)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    sys.exit(1 if sweep(a.cases, a.seed) else 0)
