@@ -1273,16 +1273,19 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
     }
   }
   // skinny M (decode steps): 64x64 tiles when the 128x128 grid would leave most CUs idle
-  if (fast && A_KC && B_KC && g.nsplit == 1 && tiles < 192 && g.epi < EPI_D0 &&
+  static const int64_t skinny_tiles = getenv("GCT_SKINNY_TILES") ? atoll(getenv("GCT_SKINNY_TILES")) : 192;   // experiment knob
+  if (fast && A_KC && B_KC && g.nsplit == 1 && tiles < skinny_tiles && g.epi < EPI_D0 &&
       (g.b_nper >= g.N || g.b_nper % 64 == 0)) {
     // ... and the panel kernel (whole reduction in one workgroup, one launch) when even those are few
     static const bool no_panel = getenv("GCT_GEMM_NO_PANEL") != nullptr;   // A/B switch for benchmarks
     if (!no_panel && g.K % 256 == 0 && g.lda * 4 * 33 < (1ll << 31) && g.ldb * 4 * 65 < (1ll << 31) &&
         (g.c_nper >= g.N || g.c_nper % 64 == 0)) {
       const int64_t tm32 = (g.M + 31) / 32;
-      if (g.N % 32 == 0 && (g.b_nper >= g.N || g.b_nper % 32 == 0) && tm32 * (g.N / 32) <= 384)
+      static const int64_t cap32 = getenv("GCT_PANEL_MAX32") ? atoll(getenv("GCT_PANEL_MAX32")) : 4096;  // knobs; 4096: +9 % / +3 % per decode step at n = 1024 / 4096 over 384
+      static const int64_t cap64 = getenv("GCT_PANEL_MAX64") ? atoll(getenv("GCT_PANEL_MAX64")) : 768;
+      if (g.N % 32 == 0 && (g.b_nper >= g.N || g.b_nper % 32 == 0) && tm32 * (g.N / 32) <= cap32)
         return launch_panel<32>(g, st);
-      if (g.N % 64 == 0 && tm32 * (g.N / 64) <= 768) return launch_panel<64>(g, st);
+      if (g.N % 64 == 0 && tm32 * (g.N / 64) <= cap64) return launch_panel<64>(g, st);
     }
     const int64_t st_ = ((g.M + 63) / 64) * ((g.N + 63) / 64);
     const int64_t nkt = g.K / BK;
