@@ -1273,8 +1273,8 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
     }
   }
   // skinny M (decode steps): 64x64 tiles when the 128x128 grid would leave most CUs idle
-  static const int64_t skinny_tiles = getenv("GCT_SKINNY_TILES") ? atoll(getenv("GCT_SKINNY_TILES")) : 192;   // experiment knob
-  if (fast && A_KC && B_KC && g.nsplit == 1 && tiles < skinny_tiles && g.epi < EPI_D0 &&
+  // (192: with more tiles the bf16x6 kernel wins even on half the CUs -- decode at n >= 6144 lost 5-8 % with 384)
+  if (fast && A_KC && B_KC && g.nsplit == 1 && tiles < 192 && g.epi < EPI_D0 &&
       (g.b_nper >= g.N || g.b_nper % 64 == 0)) {
     // ... and the panel kernel (whole reduction in one workgroup, one launch) when even those are few
     static const bool no_panel = getenv("GCT_GEMM_NO_PANEL") != nullptr;   // A/B switch for benchmarks
