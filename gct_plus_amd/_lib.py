@@ -64,6 +64,7 @@ SIGNATURES = {
     "gct_ce_fwd": (I32, [P, P, P, P, I64, I32, I64, P]),
     "gct_ce_bwd": (I32, [P, P, P, P, I64, I32, I64, P]),
     "gct_attn_decode": (I32, [P, I64, P, P, I64, I64, P, I64, P, I64, I32, I32, I32, I32, F32, P, I32, P, P, I64, P, P]),
+    "gct_attn_decode_z": (I32, [P, I64, I32, P, I64, I32, I32, P, I64, I64, I32, P, I64, P, P, I64, I32, I32, I32, I32, F32, P]),
     "gct_decode_embed": (I32, [P, I64, P, I32, P, I32, P, P, I32, I32, F32, P]),
     "gct_decode_advance": (I32, [P, P]),
     "gct_select_token": (I32, [P, I32, P, I64, I32, P, I64, P, P, I32, I32, I64, I64, U64, P, I32, P, P]),
@@ -77,7 +78,7 @@ SIGNATURES = {
     "gct_add": (I32, [P, P, P, I64, P]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 

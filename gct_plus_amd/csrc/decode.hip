@@ -97,6 +97,102 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
   }
 }
 
+// Cross-attention of one decode step over the LATENT memory itself.  The cross-attention keys / values of the
+// reference are projections of e_j = fc_z(z_j): k_{j,h} = G_h z_j + c_h, v_{j,h} = H_h z_j + d_h with G_h = W_k,h W_z
+// and H_h = W_v,h W_z (64 x latent).  A score q_h . k_{j,h} is (G_h^T q_h) . z_j plus a term that is the same for
+// every key of the row (softmax-invariant), and sum_j p_j v_{j,h} = H_h (sum_j p_j z_j) + d_h.  With G_h^T folded into
+// the query projection and H_h into the output projection (host side, once per sequence), a step reads the z rows of
+// a sample ONCE for all heads -- latent x 4 B per key instead of 2 x d_model x 4 B (8 x less at latent 128, d 512).
+// One workgroup per sample: z rows -> LDS, scores for (head, key) pairs, softmax per head, context (head, latent).
+// The n_c condition rows of a cond2lat memory are not functions of z: they keep explicit per-head keys / values
+// (shifted by -c_h / -d_h on the host so that the two kinds of key share one softmax).
+__global__ __launch_bounds__(256) void attn_decode_z_kernel(
+    const float* __restrict__ q, int64_t ldq, int qoff, const float* __restrict__ z, int64_t z_batch, int lat, int Le,
+    const float* __restrict__ ckv, int64_t ckv_batch, int64_t ld_ckv, int nc, int d, const uint8_t* __restrict__ valid,
+    int64_t valid_sb, const int32_t* __restrict__ klen, float* __restrict__ out, int64_t ldo, int ooff, int H, int dk,
+    float scale) {
+  extern __shared__ __attribute__((aligned(16))) float zl[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Lk = nc + Le, zs_ld = lat + 4, lat4 = lat >> 2, Lp = (Lk + 3) & ~3;
+  float* zs = zl;                              // [Le][lat + 4]
+  float* qs = zl + (size_t)Le * zs_ld;         // [H][lat]
+  float* ps = qs + (size_t)H * lat;            // [H][Lp]
+  // keys beyond klen[b] are masked and the sample sees a key: weight exactly 0, never read
+  const int Lvis = klen ? (klen[b] < Lk ? klen[b] : Lk) : Lk;
+  const int ncv = nc < Lvis ? nc : Lvis, nz = Lvis - ncv;
+  const float* zb = z + (int64_t)b * z_batch;
+  const float* qb = q + (int64_t)b * ldq;
+  for (int i = tid; i < nz * lat4; i += 256) {
+    const int row = i / lat4, c4 = i - row * lat4;
+    *reinterpret_cast<float4*>(zs + row * zs_ld + c4 * 4) = *reinterpret_cast<const float4*>(zb + (int64_t)row * lat + c4 * 4);
+  }
+  for (int i = tid; i < H * lat4; i += 256)
+    *reinterpret_cast<float4*>(qs + i * 4) = *reinterpret_cast<const float4*>(qb + qoff + i * 4);
+  __syncthreads();
+  const uint8_t* vl = valid ? valid + (int64_t)b * valid_sb : nullptr;
+  for (int i = tid; i < H * nz; i += 256) {          // consecutive lanes: consecutive keys of one head
+    const int h = i / nz, j = i - h * nz;
+    const float* zr = zs + j * zs_ld;
+    const float* qh = qs + h * lat;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int c = 0; c < lat; c += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(qh + c), k4 = *reinterpret_cast<const float4*>(zr + c);
+      s0 = fmaf(a.x, k4.x, s0); s1 = fmaf(a.y, k4.y, s1); s2 = fmaf(a.z, k4.z, s2); s3 = fmaf(a.w, k4.w, s3);
+    }
+    float sc = ((s0 + s1) + (s2 + s3)) * scale;
+    if (vl && vl[ncv + j] == 0) sc = -1e9f;          // masked_fill(mask == 0, -1e9)
+    ps[h * Lp + ncv + j] = sc;
+  }
+  for (int i = tid; i < H * ncv; i += 256) {         // explicit condition rows: q_h . k'_{j,h} over the head dim
+    const int h = i / ncv, j = i - h * ncv;
+    const float* kr = ckv + (int64_t)b * ckv_batch + (int64_t)j * ld_ckv + h * dk;
+    const float* qh = qb + h * dk;
+    float sc = 0.f;
+    for (int c = 0; c < dk; ++c) sc = fmaf(qh[c], kr[c], sc);
+    sc *= scale;
+    if (vl && vl[j] == 0) sc = -1e9f;
+    ps[h * Lp + j] = sc;
+  }
+  __syncthreads();
+  for (int h = wave; h < H; h += 4) {                // softmax of one head per wave
+    float* pr = ps + h * Lp;
+    float m = -INFINITY;
+    for (int j = lane; j < Lvis; j += 64) m = fmaxf(m, pr[j]);
+    m = gct_wave_max(m);
+    float l = 0.f;
+    for (int j = lane; j < Lvis; j += 64) {
+      const float e = expf(pr[j] - m);
+      pr[j] = e;
+      l += e;
+    }
+    l = gct_wave_sum(l);
+    const float inv = 1.0f / l;
+    for (int j = lane; j < Lvis; j += 64) pr[j] *= inv;
+  }
+  __syncthreads();
+  float* ob = out + (int64_t)b * ldo;
+  for (int i = tid; i < H * lat4; i += 256) {        // context of head h in the latent space: sum_j p_j z_j
+    const int h = i / lat4, c4 = i - h * lat4;
+    const float* pr = ps + h * Lp + ncv;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < nz; ++j) {
+      const float w = pr[j];
+      const float4 z4 = *reinterpret_cast<const float4*>(zs + j * zs_ld + c4 * 4);
+      acc.x = fmaf(w, z4.x, acc.x); acc.y = fmaf(w, z4.y, acc.y); acc.z = fmaf(w, z4.z, acc.z); acc.w = fmaf(w, z4.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(ob + ooff + h * lat + c4 * 4) = acc;
+  }
+  if (nc > 0) {
+    for (int i = tid; i < d; i += 256) {             // condition rows: sum_j p_j v'_{j,h}, head-major like the reference
+      const int h = i / dk;
+      const float* pr = ps + h * Lp;
+      float acc = 0.f;
+      for (int j = 0; j < ncv; ++j) acc = fmaf(pr[j], ckv[(int64_t)b * ckv_batch + (int64_t)j * ld_ckv + d + i], acc);
+      ob[i] = acc;
+    }
+  }
+}
+
 // x[b][:] = table[ys[b][*pos]] * scale + pe[pe_off + *pos][:]   (Embeddings + PositionalEncoding of ONE position)
 __global__ __launch_bounds__(256) void decode_embed_kernel(const int64_t* __restrict__ ys, int64_t ld_ys,
                                                            const int32_t* __restrict__ pos, int pe_off,
@@ -217,6 +313,35 @@ extern "C" int gct_attn_decode(const float* q, int64_t ldq, float* k, float* v,
   else if (dk == 32) hipLaunchKernelGGL(attn_decode_kernel<32>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale, pos, cache_off, knew, vnew, ldn, klen);
   else hipLaunchKernelGGL(attn_decode_kernel<16>, grid, block, 0, st, q, ldq, k, v, kv_row, kv_batch, valid, valid_sb, o, ldo, n, H, Lc, scale, pos, cache_off, knew, vnew, ldn, klen);
   GCT_LAUNCH_CHECK("attn_decode");
+  return GCT_OK;
+}
+
+extern "C" int gct_attn_decode_z(const float* q, int64_t ldq, int qoff, const float* z, int64_t z_batch, int lat, int Le,
+                                 const float* ckv, int64_t ckv_batch, int64_t ld_ckv, int nc, const uint8_t* valid,
+                                 int64_t valid_sb, const int32_t* klen, float* out, int64_t ldo, int ooff, int n, int H,
+                                 int dk, float scale, void* stream) {
+  GCT_CHECK_ARG(q && z && out && n >= 0 && H > 0 && dk > 0 && Le >= 0 && nc >= 0 && nc + Le > 0 && nc + Le <= 259,
+                "attn_decode_z: bad args");
+  GCT_CHECK_ARG(lat > 0 && lat % 4 == 0 && lat <= 128 && Le <= 256, "attn_decode_z: latent size %d / %d rows unsupported", lat, Le);
+  GCT_CHECK_ARG(nc == 0 || (ckv && ld_ckv >= 2 * (int64_t)H * dk), "attn_decode_z: condition rows without their keys / values");
+  GCT_CHECK_ARG(ldq % 4 == 0 && qoff % 4 == 0 && ooff % 4 == 0 && ldo % 4 == 0 && z_batch % 4 == 0 && gct_aligned16(q) &&
+                    gct_aligned16(z) && gct_aligned16(out),
+                "attn_decode_z: operands must be 16-B aligned");
+  if (n == 0) return GCT_OK;
+  const size_t lds = ((size_t)Le * (lat + 4) + (size_t)H * lat + (size_t)H * ((nc + Le + 3) & ~3)) * sizeof(float);
+  GCT_CHECK_ARG(lds <= 160 * 1024, "attn_decode_z: %zu bytes of LDS needed", lds);
+  static size_t lds_set = 0;
+  if (lds > 48 * 1024 && lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_decode_z_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e != hipSuccess) {
+      gct_set_error("attn_decode_z: cannot reserve LDS: %s", hipGetErrorString(e));
+      return GCT_ERR_HIP;
+    }
+    lds_set = 160 * 1024;
+  }
+  hipLaunchKernelGGL(attn_decode_z_kernel, dim3((unsigned)n), dim3(256), lds, (hipStream_t)stream, q, ldq, qoff, z, z_batch,
+                     lat, Le, ckv, ckv_batch, ld_ckv, nc, H * dk, valid, valid_sb, klen, out, ldo, ooff, H, dk, scale);
+  GCT_LAUNCH_CHECK("attn_decode_z");
   return GCT_OK;
 }
 

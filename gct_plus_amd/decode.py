@@ -33,6 +33,9 @@ from ._lib import check
 # path (bf16x6).  Measured on MI355X: n = 1100 / 1536 / 2048 / 3000 take 2.18 / 2.32 / 2.39 / 3.04 ms per token on the
 # general path against 2.27 / 2.46 / 2.58 / 3.74 on the skinny kernels; `GCT_DECODE_SKINNY_BELOW` overrides
 SKINNY_BELOW = int(os.environ.get("GCT_DECODE_SKINNY_BELOW", "1024"))
+# cross-attention of a step over the latent rows themselves (gct_attn_decode_z) instead of per-layer K / V projections of
+# the memory; `GCT_DECODE_ZATTN=0` keeps the projected K / V (the A/B switch; also taken when the latent is too wide)
+ZATTN = os.environ.get("GCT_DECODE_ZATTN", "1") != "0"
 
 
 class KVDecoder:
@@ -62,23 +65,26 @@ class KVDecoder:
         nc = dec.nconds
         c2l = (not self.c2d) and dec.use_cond2lat and nc > 0
         self.z, self.src_mask_in, self.dconds = z, src_mask, dconds
+        self.zattn = bool(ZATTN and lat % 4 == 0 and lat <= 128 and Le <= 256 and self.H * lat <= 2 * d)
         z2 = z.reshape(n * Le, lat).float().contiguous()
-        ez = torch.empty(n * Le, d, device=dev)
-        ops.linear_fwd(z2, [dec.fc_z.weight], [dec.fc_z.bias], [ez], d)
-        Lk, e = Le, ez
+        Lk, e = Le, None
+        if not self.zattn:
+            e = ez = torch.empty(n * Le, d, device=dev)
+            ops.linear_fwd(z2, [dec.fc_z.weight], [dec.fc_z.bias], [ez], d)
         sv = ops.to_mask_u8(src_mask).view(n, Le)
         if c2l:
             Lk = Le + nc
             cl = ops.small_linear_fwd(dconds.float().contiguous(), dec.embed_cond2lat.weight,
                                       dec.embed_cond2lat.bias)
-            e = torch.empty(n * Lk, d, device=dev)
-            ops.copy_rows(cl, nc, 0, e, Lk, 0, n * nc, nc, d)
-            ops.copy_rows(ez, Le, 0, e, Lk, nc, n * Le, Le, d)
+            if not self.zattn:
+                e = torch.empty(n * Lk, d, device=dev)
+                ops.copy_rows(cl, nc, 0, e, Lk, 0, n * nc, nc, d)
+                ops.copy_rows(ez, Le, 0, e, Lk, nc, n * Le, Le, d)
             sv = torch.cat([torch.ones(n, nc, dtype=torch.uint8, device=dev), sv], dim=1)
         T = int(max_total_len) + self.off              # cache rows: condition tokens (cond2dec) + tokens
         if T > 256 or Lk > 256:
             raise ValueError("decode lengths above 256 are not supported by gct_attn_decode")
-        shape = (n, Lk, T, str(dev))
+        shape = (n, Lk, T, str(dev), self.zattn, lat)
         if shape != self._shape:
             # new geometry: new buffers, and the graphs captured against the old ones are dropped with them
             # (they hold raw pointers: replaying them after a reallocation would write freed memory)
@@ -86,7 +92,22 @@ class KVDecoder:
             self.graph_replay = True
             self._shape = shape
             self.n, self.Lk, self.T = n, Lk, T
-            self.cross_kv = [torch.empty(n * Lk, 2 * d, device=dev) for _ in dec.layers]
+            self.nz = self.H * lat                     # width of the folded query / latent context (zattn)
+            self.nq = (d if c2l else 0) + self.nz
+            if self.zattn:
+                # folded projections of all layers in ONE flat buffer (its bf16 planes serve the bf16x6 GEMMs)
+                per = 2 * self.nq * d
+                self.zflat = torch.empty(len(dec.layers) * per, device=dev)
+                self.zq_w = [self.zflat[i * per:i * per + self.nq * d].view(self.nq, d) for i in range(len(dec.layers))]
+                self.zo_w = [self.zflat[i * per + self.nq * d:(i + 1) * per].view(d, self.nq) for i in range(len(dec.layers))]
+                self.zq_b = [torch.empty(self.nq, device=dev) for _ in dec.layers]
+                self.zo_b = [torch.empty(d, device=dev) for _ in dec.layers]
+                self.ckv = [torch.empty(n * nc, 2 * d, device=dev) if c2l else None for _ in dec.layers]
+                self.z3 = torch.empty(n, Le, lat, device=dev)     # captured graphs read the latent rows from here
+                self.zplanes = None
+                self.cross_kv = None
+            else:
+                self.cross_kv = [torch.empty(n * Lk, 2 * d, device=dev) for _ in dec.layers]
             self.kc = [torch.empty(n, T, d, device=dev) for _ in dec.layers]
             self.vc = [torch.empty(n, T, d, device=dev) for _ in dec.layers]
             self.valid = torch.zeros(n, T, dtype=torch.uint8, device=dev)
@@ -105,7 +126,8 @@ class KVDecoder:
             # few rows: the skinny split-K kernels; many rows (n >= 1024): the general path, i.e. the bf16x6 kernels
             self.gemm_kw = dict(splitk_ws=self.ws) if n < SKINNY_BELOW else dict(ws=self.ws)
             f = lambda *sh: torch.empty(*sh, device=dev)                # noqa: E731
-            self.buf = dict(x=f(n, d), x2=f(n, d), qkv=f(n, 3 * d), o=f(n, d), xa=f(n, d), q2=f(n, d), o2=f(n, d),
+            qw = self.nq if self.zattn else d
+            self.buf = dict(x=f(n, d), x2=f(n, d), qkv=f(n, 3 * d), o=f(n, d), xa=f(n, d), q2=f(n, qw), o2=f(n, qw),
                             xb=f(n, d), pre=f(n, dff), hdn=f(n, dff), xc=[f(n, d), f(n, d)], y=f(n, d),
                             logits=f(n, V))
         self.src_valid.copy_(sv)
@@ -114,10 +136,60 @@ class KVDecoder:
         cnt = sv.sum(1, dtype=torch.int32)
         prefix = (sv[:, :-1] >= sv[:, 1:]).all(1) if Lk > 1 else torch.ones(n, dtype=torch.bool, device=dev)
         self.src_klen.copy_(torch.where(prefix & (cnt > 0), cnt, torch.full_like(cnt, Lk)))
+        if self.zattn:
+            self.z3.copy_(z2.view(n, Le, lat))
+            self._fold_cross(cl.view(n * nc, d) if c2l else None)
+            return
         for li, layer in enumerate(dec.layers):                    # cross K/V: once per sequence
             kv, a = self.cross_kv[li], layer.attn_2
             ops.linear_fwd(e, [a.k_linear.weight, a.v_linear.weight], [a.k_linear.bias, a.v_linear.bias],
                            [kv, kv[:, d:]], 2 * d)
+
+    def _fold_cross(self, cl):
+        """Once per sequence, weights only (+ the n_c condition rows): the cross-attention of layer l over the memory
+        e = fc_z(z) is rewritten over z itself (gct_attn_decode_z).  With G = W_k W_z, Hm = W_v W_z (d x latent) and
+        the block-diagonal BD[h*lat + c, h*dk + r] = G[h*dk + r, c]:
+            folded query    q' = BD (W_q x + b_q)            -> zq_w = [W_q ; BD W_q], zq_b = [b_q ; BD b_q]
+            folded output   y  = W_o (o_cond + BDH ctx) + b_o + W_o d   with d = W_v b_z + b_v
+        (the key-side constant c = W_k b_z + b_k shifts every score of a row equally and drops out of the softmax; the
+        condition rows keep explicit keys / values, shifted by -c / -d so that they share the softmax and the bias)."""
+        dec, d, H, dk, dev = self.dec, self.d, self.H, self.dk, self.zflat.device
+        lat = self.nz // H
+        Wz, bz = dec.fc_z.weight, dec.fc_z.bias
+        WzT = Wz.t().contiguous()                                  # [lat, d]
+        hh = torch.arange(H, device=dev)
+        off = self.nq - self.nz                                    # d with condition rows, else 0
+
+        def blockdiag(M):                                          # M [d, lat] -> [H*lat, d]
+            bd = torch.zeros(H, lat, H, dk, device=dev)
+            bd[hh, :, hh, :] = M.view(H, dk, lat).transpose(1, 2)
+            return bd.view(H * lat, d)
+
+        for li, layer in enumerate(dec.layers):
+            a = layer.attn_2
+            G, Hm = torch.empty(d, lat, device=dev), torch.empty(d, lat, device=dev)
+            ops.linear_fwd(a.k_linear.weight, [WzT], [None], [G], lat)             # W_k W_z
+            ops.linear_fwd(a.v_linear.weight, [WzT], [None], [Hm], lat)            # W_v W_z
+            cv = torch.empty(2, d, device=dev)                                      # c = W_k b_z + b_k ; d = W_v b_z + b_v
+            ops.linear_fwd(bz.view(1, d), [a.k_linear.weight], [a.k_linear.bias], [cv[0:1]], d)
+            ops.linear_fwd(bz.view(1, d), [a.v_linear.weight], [a.v_linear.bias], [cv[1:2]], d)
+            BD, BDH = blockdiag(G), blockdiag(Hm)
+            qw, ow = self.zq_w[li], self.zo_w[li]
+            ops.linear_fwd(BD, [a.q_linear.weight.t().contiguous()], [None], [qw[off:]], d)          # BD W_q
+            ops.linear_fwd(BD, [a.q_linear.bias.view(1, d)], [None], [self.zq_b[li][off:].view(-1, 1)], 1)
+            ops.linear_fwd(a.out.weight, [BDH], [None], [ow[:, off:]], self.nq)    # W_o BDH^T^T: rows of BDH are its N
+            ops.linear_fwd(cv[1:2], [a.out.weight], [a.out.bias], [self.zo_b[li].view(1, d)], d)     # W_o d + b_o
+            if off:
+                qw[:off].copy_(a.q_linear.weight)
+                self.zq_b[li][:off].copy_(a.q_linear.bias)
+                ow[:, :off].copy_(a.out.weight)
+                kv = self.ckv[li]                                   # condition rows: k - c | v - d
+                ops.linear_fwd(cl, [a.k_linear.weight, a.v_linear.weight], [a.k_linear.bias, a.v_linear.bias],
+                               [kv, kv[:, d:]], 2 * d)
+                kv.view(-1, 2, d).sub_(cv.view(1, 2, d))
+        if ops.gemm_get_mode() == ops.GEMM_BF16X6:
+            self.zplanes = ops.split_planes(self.zflat, self.zplanes)
+            ops.register_planes(self.zflat, self.zplanes)
 
     # -------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -174,12 +246,20 @@ class KVDecoder:
             ops.linear_fwd(B["o"], [a1.out.weight], [a1.out.bias], [B["xa"]], d,
                            epi=ops.EPI_DROP_RESID, resid=x, **self.gemm_kw)
             ops.norm_fwd(B["xa"], layer.norm_2.alpha, layer.norm_2.bias, layer.norm_2.eps, out=B["x2"])
-            ops.linear_fwd(B["x2"], [a2.q_linear.weight], [a2.q_linear.bias], [B["q2"]], d, **self.gemm_kw)
-            kv = self.cross_kv[li]
-            ops.attn_decode(B["q2"], d, kv, kv[:, d:], 2 * d, self.Lk * 2 * d, self.src_valid, self.Lk,
-                            B["o2"], n, self.H, self.Lk, self.dk, klen=self.src_klen)
-            ops.linear_fwd(B["o2"], [a2.out.weight], [a2.out.bias], [B["xb"]], d,
-                           epi=ops.EPI_DROP_RESID, resid=B["xa"], **self.gemm_kw)
+            if self.zattn:
+                off = self.nq - self.nz
+                ops.linear_fwd(B["x2"], [self.zq_w[li]], [self.zq_b[li]], [B["q2"]], self.nq, **self.gemm_kw)
+                ops.attn_decode_z(B["q2"], off, self.z3, self.ckv[li], self.Lk - self.z3.shape[1], self.src_valid,
+                                  B["o2"], off, n, self.H, self.dk, klen=self.src_klen)
+                ops.linear_fwd(B["o2"], [self.zo_w[li]], [self.zo_b[li]], [B["xb"]], d,
+                               epi=ops.EPI_DROP_RESID, resid=B["xa"], **self.gemm_kw)
+            else:
+                ops.linear_fwd(B["x2"], [a2.q_linear.weight], [a2.q_linear.bias], [B["q2"]], d, **self.gemm_kw)
+                kv = self.cross_kv[li]
+                ops.attn_decode(B["q2"], d, kv, kv[:, d:], 2 * d, self.Lk * 2 * d, self.src_valid, self.Lk,
+                                B["o2"], n, self.H, self.Lk, self.dk, klen=self.src_klen)
+                ops.linear_fwd(B["o2"], [a2.out.weight], [a2.out.bias], [B["xb"]], d,
+                               epi=ops.EPI_DROP_RESID, resid=B["xa"], **self.gemm_kw)
             ops.norm_fwd(B["xb"], layer.norm_3.alpha, layer.norm_3.bias, layer.norm_3.eps, out=B["x2"])
             ops.linear_fwd(B["x2"], [ff.linear_1.weight], [ff.linear_1.bias], [B["hdn"]],
                            B["hdn"].shape[1], epi=ops.EPI_GELU_DROP, pre=B["pre"], **self.gemm_kw)

@@ -686,6 +686,18 @@ def attn_decode(q, ldq, k, v, kv_row, kv_batch, valid_u8, valid_sb, out, n, H, L
                                _p(knew), _p(vnew), ldn, _p(klen), _st()), "gct_attn_decode")
 
 
+def attn_decode_z(q, qoff, z, ckv, nc, valid_u8, out, ooff, n, H, dk, klen=None):
+    """Cross-attention of one decode step over the latent rows z [n, Le, lat] (gct_attn_decode_z): q [n, ldq] holds the
+    plain query in columns [0, H*dk) (read only with condition rows) and the G^T-folded query at qoff; ckv [n*nc, >= 2*H*dk]
+    the shifted keys | values of the nc condition rows; out [n, ldo] gets the per-head latent context at ooff (and the
+    condition rows' part in columns [0, H*dk) when nc > 0)."""
+    Le, lat = z.shape[1], z.shape[2]
+    check(_L().gct_attn_decode_z(_p(q), q.stride(0), qoff, _p(z), z.stride(0), lat, Le, _p(ckv),
+                                 0 if ckv is None else nc * ckv.stride(0), 0 if ckv is None else ckv.stride(0), nc,
+                                 _p(valid_u8), 0 if valid_u8 is None else valid_u8.stride(0), _p(klen), _p(out),
+                                 out.stride(0), ooff, n, H, dk, 1.0 / math.sqrt(dk), _st()), "gct_attn_decode_z")
+
+
 def select_token(logits2d, ys, pos, valid_u8, done_u8, mode, pad_id, eos_id, seed=0, probs_out=None, pos_dev=None,
                  valid_off=0, seed_dev=None):
     n, V = logits2d.shape

@@ -37,7 +37,7 @@ extern "C" {
 #define GCT_ERR_ARG (-1)  /* bad shape / alignment / null pointer            */
 #define GCT_ERR_HIP (-2)  /* a HIP runtime call failed (launch error)        */
 
-#define GCT_ABI_VERSION 7
+#define GCT_ABI_VERSION 8
 
 int gct_version(void);
 const char* gct_last_error(void);
@@ -322,6 +322,22 @@ int gct_attn_decode(const float* q, int64_t ldq, float* k, float* v, int64_t kv_
                     int64_t kv_batch, const uint8_t* valid, int64_t valid_sb, float* o, int64_t ldo,
                     int n, int H, int Lc, int dk, float scale, const int32_t* pos, int cache_off,
                     const float* knew, const float* vnew, int64_t ldn, const int32_t* klen, void* stream);
+/* gct_attn_decode_z: the cross-attention of a decode step (Model/layers.py:73-76 attn_2 over e_outputs = fc_z(z),
+ * Model/vaetf.py:75-95) computed over the LATENT rows themselves.  k_{j,h} = G_h z_j + c_h and v_{j,h} = H_h z_j + d_h
+ * with G_h = W_k,h W_z, H_h = W_v,h W_z, so score_{j,h} = (G_h^T q_h) . z_j + (a term equal for all keys of the row)
+ * and sum_j p_j v_{j,h} = H_h sum_j p_j z_j + d_h: the caller folds G_h^T into the query projection and H_h into the
+ * output projection once per sequence, and a step reads lat floats per key instead of 2 * d_model.
+ *   q    [n][ldq]: columns [qoff, qoff + H*lat) hold q'_h = G_h^T q_h; columns [0, H*dk) the plain q (read only if nc > 0)
+ *   z    row j of sample b at z + b*z_batch + j*lat, Le rows (lat % 4 == 0, lat <= 128, Le <= 256)
+ *   ckv  (nc > 0: cond2lat memory, Model/cvaetf.py:86-96) the nc leading keys that are not functions of z: row j of
+ *        sample b at ckv + b*ckv_batch + j*ld_ckv holds k'_j = k_j - c (H*dk floats) then v'_j = v_j - d (H*dk floats)
+ *   valid (nullable) uint8 [n][>= nc + Le], 0 => -1e9 (condition rows first); klen (nullable) as in gct_attn_decode
+ *   out  [n][ldo]: columns [ooff, ooff + H*lat) = sum_j p_j z_j per head; columns [0, H*dk) = sum_{j < nc} p_j v'_j
+ *        (written only if nc > 0). */
+int gct_attn_decode_z(const float* q, int64_t ldq, int qoff, const float* z, int64_t z_batch, int lat, int Le,
+                      const float* ckv, int64_t ckv_batch, int64_t ld_ckv, int nc, const uint8_t* valid,
+                      int64_t valid_sb, const int32_t* klen, float* out, int64_t ldo, int ooff, int n, int H, int dk,
+                      float scale, void* stream);
 /* x[b] = table[ys[b][*pos]] * scale + pe[pe_off + *pos] (Embeddings + PositionalEncoding of one position, eval mode) */
 int gct_decode_embed(const int64_t* ys, int64_t ld_ys, const int32_t* pos, int pe_off, const float* table,
                      int vocab, const float* pe, float* out, int n, int d, float scale, void* stream);

@@ -236,3 +236,85 @@ def test_kv_decode_source_masks_prefix_holes_and_empty(mtype):
     assert int(klen[3]) == (nc if nc else Lk)      # nothing visible: all rows (uniform); only the condition rows: those
     # left-padded: with the condition rows in front (pvaetf) it is not a prefix either
     assert int(klen[2]) == Lk
+
+
+@pytest.mark.parametrize("nc,lat,H,dk,Le", [(0, 128, 8, 64, 80), (3, 128, 8, 64, 77), (0, 16, 4, 16, 19), (3, 32, 2, 32, 5),
+                                            (0, 64, 4, 16, 200), (3, 8, 4, 16, 1)])
+def test_attn_decode_z_equals_attention_over_projected_memory(nc, lat, H, dk, Le):
+    """gct_attn_decode_z (cross-attention of a decode step over the latent rows, keys / values never projected) against
+    the reference formulation in fp64: memory = [cond2lat rows ; fc_z(z)], k = W_k mem + b_k, v = W_v mem + b_v,
+    softmax(q k^T / sqrt(dk), masked_fill -1e9) v (Model/sublayers.py:29-41).  Masks: full, prefix (with klen), holes, and a
+    sample that sees no key (uniform over all keys, like the reference)."""
+    from gct_plus_amd import ops
+    d, n = H * dk, 9
+    g = torch.Generator().manual_seed(100 + lat + Le)
+    rd = lambda *s, sc=1.0: (torch.randn(*s, generator=g, dtype=torch.float64) * sc)       # noqa: E731
+    Wz, bz = rd(d, lat, sc=lat ** -0.5), rd(d, sc=0.3)
+    Wk, bk, Wv, bv = rd(d, d, sc=d ** -0.5), rd(d, sc=0.3), rd(d, d, sc=d ** -0.5), rd(d, sc=0.3)
+    q, z, cond = rd(n, d), rd(n, Le, lat), rd(n, nc, d)
+    Lk = nc + Le
+    valid = torch.ones(n, Lk, dtype=torch.uint8)
+    klen = torch.full((n,), Lk, dtype=torch.int32)
+    for b in range(n):
+        kind = b % 4
+        if kind == 1:                                  # visible prefix: the kernel may stop at klen
+            ln = int(torch.randint(nc + (0 if nc else 1), Lk + 1, (1,), generator=g))
+            ln = max(ln, 1)
+            valid[b, ln:] = 0
+            klen[b] = ln
+        elif kind == 2:                                # holes: every row is read
+            valid[b, nc:] = (torch.rand(Le, generator=g) < 0.6).to(torch.uint8)
+        elif kind == 3 and nc == 0:                    # no visible key at all
+            valid[b] = 0
+    mem = torch.cat([cond, z @ Wz.t() + bz], 1)                                  # [n, Lk, d]
+    k = (mem @ Wk.t() + bk).view(n, Lk, H, dk).transpose(1, 2)
+    v = (mem @ Wv.t() + bv).view(n, Lk, H, dk).transpose(1, 2)
+    s = (q.view(n, H, 1, dk) @ k.transpose(-1, -2)) / dk ** 0.5                   # [n, H, 1, Lk]
+    s = s.masked_fill(valid.view(n, 1, 1, Lk) == 0, -1e9)
+    ref = (s.softmax(-1) @ v).transpose(1, 2).reshape(n, d)
+    # the folding (decode.KVDecoder._fold_cross), here in fp64
+    G, Hm = Wk @ Wz, Wv @ Wz                                                      # [d, lat]
+    c, dv = Wk @ bz + bk, Wv @ bz + bv
+    qf = torch.einsum("hrc,nhr->nhc", G.view(H, dk, lat), q.view(n, H, dk)).reshape(n, H * lat)
+    qbuf = torch.cat([q, qf], 1).float().contiguous().cuda()                      # plain q | folded q
+    ckv = None
+    if nc:
+        ck = cond @ Wk.t() + bk - c
+        cvv = cond @ Wv.t() + bv - dv
+        ckv = torch.cat([ck, cvv], 2).view(n * nc, 2 * d).float().contiguous().cuda()
+    out = torch.zeros(n, d + H * lat, device="cuda")
+    ops.attn_decode_z(qbuf, d, z.float().contiguous().cuda(), ckv, nc, valid.cuda(), out, d, n, H, dk, klen=klen.cuda())
+    ctx = out[:, d:].cpu().double().view(n, H, lat)
+    o = torch.einsum("hrc,nhc->nhr", Hm.view(H, dk, lat), ctx).reshape(n, d) + dv
+    if nc:
+        o = o + out[:, :d].cpu().double()
+    err = (o - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_kv_decode_latent_cross_attention_vs_projected_keys():
+    """The two cross-attention forms of the cached decoder (over the latent rows / over projected K, V): same token ids and
+    logits within fp32 rounding at full size, with cond2lat condition rows in the memory."""
+    from gct_plus_amd import decode
+    from gct_plus_amd.decode import KVDecoder
+    model = build("pscavaetf", full=True, seed=5)
+    n, Le = 48, 33
+    g = torch.Generator().manual_seed(2)
+    z = torch.randn(n, Le, 128, generator=g).cuda()
+    dconds = torch.randn(n, 3, generator=g).cuda()
+    lens = torch.randint(5, Le + 1, (n,), generator=g)
+    src_mask = (torch.arange(Le)[None, :] < lens[:, None]).unsqueeze(1).cuda()
+    ys0 = torch.full((n, 1), synthetic.SOS_ID, dtype=torch.long, device="cuda")
+    res = {}
+    keep = decode.ZATTN
+    try:
+        for zz in (False, True):
+            decode.ZATTN = zz
+            kd = KVDecoder(model, synthetic.PAD_ID, synthetic.SOS_ID, -1)
+            kd.start(z, src_mask, dconds, max_total_len=40)
+            assert kd.zattn == zz
+            res[zz] = (kd.generate(ys0, max_strlen=30).clone(), kd.buf["logits"].clone())
+    finally:
+        decode.ZATTN = keep
+    assert torch.equal(res[False][0], res[True][0])
+    assert torch.allclose(res[False][1], res[True][1], atol=1e-4, rtol=1e-4)

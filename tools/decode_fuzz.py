@@ -91,7 +91,7 @@ def sweep(cases=30, seed=1, verbose=True):
         ties += status == "tie"
         line = (f"case {case:3d} {mtype:9s} N={kw['N']} d={d_model} h={h} dff={kw['dff']} n={n:4d} Le={Le:2d} prefix={npre:2d} "
                 f"len={max_strlen:2d} mask={mk} cond2dec={int(c2d)} eos={eos} graphs={int(graphs)} "
-                f"replayed={int(bool(getattr(kd, 'graph_replay', False)))} -> {status} {tuple(out.shape)}")
+                f"replayed={int(bool(getattr(kd, 'graph_replay', False)))} zattn={int(kd.zattn)} -> {status} {tuple(out.shape)}")
         if verbose or status == "MISMATCH":
             print(line, flush=True)
         if status == "MISMATCH":
