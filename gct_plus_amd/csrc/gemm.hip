@@ -1265,6 +1265,19 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
   const bool fast = fast_ok<A_KC, B_KC>(g, vec);
   static const int stagger_env = getenv("GCT_GEMM_STAGGER") ? atoi(getenv("GCT_GEMM_STAGGER")) : -1;
   if (A_KC && B_KC && gemm_mode() == GCT_GEMM_BF16X6 && g.epi < EPI_D0) {
+    // few 128 x 256 tiles but enough 64 x 128 ones: the small-tile bf16x6 kernel (decode steps of 2 000-4 000 rows,
+    // training at small batches)
+    static const int x6s_on = getenv("GCT_X6S") ? atoi(getenv("GCT_X6S")) : 1;          // A/B switch
+    const int64_t big = ((g.M + XBM - 1) / XBM) * ((g.N + XBN - 1) / XBN);
+    const int64_t small = ((g.M + SBM - 1) / SBM) * ((g.N + SBN - 1) / SBN);
+    // measured (tools/kernel_bench.py --suite decgemm, rows 1 024 ... 5 184): a 64 x 128 tile takes 0.75 us per K-tile
+    // alone on its CU and 1.45 us when two share it, a 128 x 256 tile 2.8 us; from K = 2 048 on the large kernel's
+    // K-split routes fill the chip and win, at K = 1 024 only while every small tile has a CU to itself
+    const int64_t nkt_ = g.K / XBK;
+    if (x6s_on && big <= 160 && small >= 96 && small <= (nkt_ <= 16 ? 512 : 256) && nkt_ <= 32 && x6s_ok(g, vec)) {
+      ++g_gemm_launches[1];
+      return launch_x6s(g, st);
+    }
     if (x6_ok<X6_FWD>(g, vec)) {
       int taken = 0;
       const int rc = launch_x6_splitk_all<X6_FWD>(g, st, skinny_ws, ws_bytes, &taken);

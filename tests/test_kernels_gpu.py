@@ -452,8 +452,11 @@ def test_linear_bf16x6_vs_fp64(ops, M, K, nper, nseg):
     refs = (x.double() @ W.t() + torch.cat(bs).double(), dy.double() @ W, dy.double().t() @ x.double(), dy.double().sum(0))
     assert res[ops.GEMM_F32][4] == 0
     x6_launches = res[ops.GEMM_BF16X6][4]
-    big = -(-M // 128) * -(-N // 128) >= 192           # smaller forward launches take the skinny-M kernel
-    expect = (1 if (big and (nseg == 1 or nper % 256 == 0)) else 0) + (1 if N % 32 == 0 else 0) + (1 if M % 32 == 0 else 0)
+    big = -(-M // 128) * -(-N // 128) >= 192           # smaller forward launches take the skinny-M kernel ...
+    small_t, nkt = -(-M // 64) * -(-N // 128), K // 32   # ... or the 64 x 128-tile bf16x6 kernel
+    x6s = (-(-M // 128) * -(-N // 256) <= 160 and 96 <= small_t <= (512 if nkt <= 16 else 256) and nkt <= 32 and
+           (nseg == 1 or nper % 128 == 0))
+    expect = (1 if (x6s or (big and (nseg == 1 or nper % 256 == 0))) else 0) + (1 if N % 32 == 0 else 0) + (1 if M % 32 == 0 else 0)
     assert x6_launches == expect, (x6_launches, expect)
     tols = ((2e-5, 2e-5), (5e-5, 5e-5), (1e-4 * math.sqrt(M / 100 + 1), 1e-4), (1e-4 * math.sqrt(M / 100 + 1), 1e-4))
     for i, what in enumerate(("fwd", "dgrad", "wgrad", "bias grad")):
@@ -615,6 +618,52 @@ def test_linear_panel_kernel_small_problems(ops, M, K, nper, nseg):
         y3 = torch.empty(M, N, device=DEV)
         ops.linear_fwd(xg, wg, bg, [y3], N, epi=ops.EPI_DROP_RESID, resid=rg, p=0.0, seed=1, site=2, splitk_ws=wsb)
         close(y3, y2.double(), 2e-5, 2e-5, "panel vs split-K route")
+
+
+@pytest.mark.parametrize("M,K,nper,nseg", [(4096, 512, 512, 1), (2050, 1024, 520, 1), (3000, 512, 512, 2), (5184, 512, 512, 1),
+                                           (2048, 512, 1536, 1), (1500, 64, 1000, 1)])
+def test_linear_bf16x6_small_tile_kernel(ops, M, K, nper, nseg):
+    """Forward GEMMs with few 128 x 256 tiles but 96-512 tiles of 64 x 128 (decode steps of 1 500-5 000 rows, small
+    training batches) take gemm_x6s_kernel: one launch, values vs fp64 at the fp32 kernels' tolerance for the plain,
+    GELU(+pre) and dropout+residual epilogues, the dropout mask of the fp32-mode launch, ragged M / N edges and
+    two weight segments."""
+    N, p, seed = nper * nseg, 0.1, 21
+    x = rnd(M, K, seed=1)
+    ws = [rnd(nper, K, seed=10 + s, scale=max(K, 64) ** -0.5) for s in range(nseg)]
+    bs = [rnd(nper, seed=20 + s) for s in range(nseg)]
+    r = rnd(M, N, seed=4)
+    xg, rg, bg = x.to(DEV), r.to(DEV), [b.to(DEV) for b in bs]
+    flat, wg = _planes_for(ops, ws)
+    u = x.double() @ torch.cat(ws).double().t() + torch.cat(bs).double()
+    outs = lambda t: [t[:, s * nper:] for s in range(nseg)]                     # noqa: E731
+    res = {}
+    try:
+        for mode in (ops.GEMM_F32, ops.GEMM_BF16X6):
+            ops.gemm_set_mode(mode)
+            k0, c0 = ops._L().gct_gemm_x6_kernel_launches(), ops.gemm_launch_counts()
+            y, pre, y1, y2 = (torch.empty(M, N, device=DEV) for _ in range(4))
+            ops.linear_fwd(xg, wg, bg, outs(y), N)
+            n_calls = 1
+            if nseg == 1:
+                ops.linear_fwd(xg, wg, bg, [y1], N, epi=ops.EPI_GELU_DROP, pre=pre, p=p, seed=seed, site=2)
+                ops.linear_fwd(xg, wg, bg, [y2], N, epi=ops.EPI_DROP_RESID, resid=rg, p=p, seed=seed, site=3)
+                n_calls = 3
+            if mode == ops.GEMM_BF16X6:        # one kernel launch per call: no split-K pair, no tail launch
+                assert ops._L().gct_gemm_x6_kernel_launches() == k0 + n_calls
+                assert ops.gemm_launch_counts()[1] == c0[1] + n_calls
+            res[mode] = [t.cpu() for t in (y, pre, y1, y2)]
+    finally:
+        ops.gemm_set_mode(ops.GEMM_BF16X6)
+        ops.unregister_planes(flat)
+    a, c = res[ops.GEMM_F32], res[ops.GEMM_BF16X6]
+    close(c[0], u, 2e-5, 2e-5, "small-tile bf16x6 vs fp64")
+    if nseg == 1:
+        close(c[1], u, 2e-5, 2e-5, "pre")
+        g_ = torch.nn.functional.gelu(u)
+        assert not (((a[2] == 0) != (c[2] == 0)) & (g_.abs() > 1e-4)).any()
+        assert not (((a[3] == r) != (c[3] == r)) & (u.abs() > 1e-4)).any()
+        close(c[2], a[2].double(), 5e-5, 1e-4, "gelu + dropout")
+        close(c[3], a[3].double(), 5e-5, 1e-4, "dropout + residual")
 
 
 def test_linear_bf16x6_split_k_over_the_whole_problem(ops):

@@ -57,7 +57,7 @@ def sweep(cases=60, seed=1, verbose=True):
         p = [0.0, 0.1][ri(0, 1)]
         seed_d, site = 1000 + case, ri(1, 9)
         x = rn(M, K)
-        ws = [rn(nper, K, scale=K ** -0.5) for _ in range(nseg)]
+        ws = [rn(nper, K, scale=max(K, 64) ** -0.5) for _ in range(nseg)]
         bs = [rn(nper) if ri(0, 5) else None for _ in range(nseg)]
         if any(b is None for b in bs):
             bs = [None] * nseg

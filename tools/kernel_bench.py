@@ -59,6 +59,23 @@ def gemm_suite(reps, only=None):
                   flush=True)
 
 
+def decgemm_suite(reps):
+    """Forward GEMMs of a KV-cached decode step (n rows) and of small training batches."""
+    dev = "cuda"
+    for M in (1024, 2048, 4096, 5184):
+        for name, K, N in (("out", 512, 512), ("q'", 512, 1024), ("out'", 1024, 512), ("qkv", 512, 1536),
+                           ("ffn1", 512, 2048), ("ffn2", 2048, 512)):
+            x = torch.randn(M, K, device=dev)
+            w = torch.randn(N * K, device=dev) * K ** -0.5
+            if ops.gemm_get_mode() == ops.GEMM_BF16X6:
+                ops.register_planes(w, ops.split_planes(w))
+            b, y = torch.randn(N, device=dev), torch.empty(M, N, device=dev)
+            wsb = torch.empty(int(ops._L().gct_linear_fwd_ws_bytes(M, K, N)) // 4 + 64, device=dev)
+            med, best = timeit(lambda: ops.linear_fwd(x, [w.view(N, K)], [b], [y], N, ws=wsb), reps)
+            fl = 2.0 * M * K * N
+            print(f"gemm {name:5s} fwd M={M} K={K} N={N}: {med*1e6:8.1f} us  {fl/med/1e12:6.1f} TF  (best {fl/best/1e12:6.1f})", flush=True)
+
+
 def attn_suite(reps, fixed=False):
     dev = "cuda"
     shapes = [("enc", 512, 8, 80, 80, 64, False), ("dec", 512, 8, 81, 81, 64, True), ("cross", 512, 8, 81, 80, 64, False)]
@@ -123,8 +140,10 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     ap.add_argument("--reps", type=int, default=10)
     a = ap.parse_args()
-    if "gemm" in a.suite:
+    if "gemm" in a.suite.split(","):
         gemm_suite(a.reps, a.only.split(",") if a.only else None)
+    if "decgemm" in a.suite:
+        decgemm_suite(a.reps)
     if "attn" in a.suite:
         attn_suite(a.reps)
         attn_suite(a.reps, fixed=True)
