@@ -971,7 +971,10 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const GemmArgs g) {
 // dependent GEMMs, each far too small to fill the chip: what counts is the latency of one launch (was: 64 x 64
 // tiles with K split 4-12 ways, 17 us, + a 9 us fix-up launch).
 // =====================================================================================
-template <int TN>
+// RAGGED (TN = 32 only): N <= 32 output columns of any count and leading dimension (the vocabulary head: 28-31
+// columns) -- weight rows beyond N are clamped to the last one (they feed columns that are never stored), the
+// epilogue is the plain bias one with scalar guarded stores.  One column of workgroups, M / 32 of them.
+template <int TN, bool RAGGED = false>
 __global__ __launch_bounds__(256) void gemm_f32_panel_kernel(const GemmArgs g) {
   constexpr int TM = 32, KC = 256, SD = KC + 4, NBL = TN / 4;   // NBL float4 of the B panel per thread and chunk
   extern __shared__ __attribute__((aligned(16))) float plds[];
@@ -995,7 +998,9 @@ __global__ __launch_bounds__(256) void gemm_f32_panel_kernel(const GemmArgs g) {
   }
 #pragma unroll
   for (int i = 0; i < NBL; ++i) {
-    const int idx = tid + 256 * i, row = idx >> 6, c4 = idx & 63;
+    const int idx = tid + 256 * i, c4 = idx & 63;
+    int64_t row = idx >> 6;
+    if (RAGGED && n0 + row > g.N - 1) row = g.N - 1 - n0;
     offb[i] = (uint32_t)(row * g.ldb + c4 * 4);
   }
   f32x4_t ra[8], rb[NBL];           // native vectors: HIP's float4 struct copies kept these arrays in scratch
@@ -1060,7 +1065,12 @@ __global__ __launch_bounds__(256) void gemm_f32_panel_kernel(const GemmArgs g) {
     if (lane < 16) {
       const int pr = lane >> 2, pc = lane & 3;
       const int64_t row0 = m0 + wm + 4 * pr, col0 = n0 + wn + 16 * u + 4 * pc;
-      if (row0 < g.M && col0 < g.N) {
+      if (RAGGED) {
+        for (int rr = 0; rr < 4; ++rr)
+          for (int cc = 0; cc < 4; ++cc)
+            if (row0 + rr < g.M && col0 + cc < g.N)
+              g.c0[(row0 + rr) * g.ldc + col0 + cc] = stg[(4 * pr + rr) * 20 + 4 * pc + cc] + (g.bias0 ? g.bias0[col0 + cc] : 0.f);
+      } else if (row0 < g.M && col0 < g.N) {
         float4 v[4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) v[rr] = *reinterpret_cast<const float4*>(stg + (4 * pr + rr) * 20 + 4 * pc);
@@ -1077,20 +1087,20 @@ __global__ __launch_bounds__(256) void gemm_f32_panel_kernel(const GemmArgs g) {
   }
 }
 
-template <int TN>
+template <int TN, bool RAGGED = false>
 int launch_panel(const GemmArgs& g, hipStream_t st) {
   constexpr size_t LDS = (size_t)(32 + TN) * 260 * sizeof(float);
   static bool attr_set = false;        // per instantiation
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_panel_kernel<TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_panel_kernel<TN, RAGGED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     if (e != hipSuccess) {
       gct_set_error("gemm_f32_panel: cannot reserve %zu bytes of LDS: %s", LDS, hipGetErrorString(e));
       return GCT_ERR_HIP;
     }
     attr_set = true;
   }
-  const int64_t tiles = ((g.M + 31) / 32) * (g.N / TN);
-  hipLaunchKernelGGL((gemm_f32_panel_kernel<TN>), dim3((unsigned)tiles), dim3(256), LDS, st, g);
+  const int64_t tiles = ((g.M + 31) / 32) * (RAGGED ? 1 : g.N / TN);
+  hipLaunchKernelGGL((gemm_f32_panel_kernel<TN, RAGGED>), dim3((unsigned)tiles), dim3(256), LDS, st, g);
   GCT_LAUNCH_CHECK("gemm_f32_panel");
   return GCT_OK;
 }
@@ -1285,6 +1295,15 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
         if (taken) ++g_gemm_launches[1];
         return rc;
       }
+    }
+  }
+  // narrow outputs (the vocabulary head, N = 28-31): the ragged panel kernel, exact fp32 MFMA, M / 32 workgroups
+  if (A_KC && B_KC && vec && g.N <= 32 && g.K % 256 == 0 && g.epi == GCT_EPI_BIAS && g.nsplit == 1 && g.b_nper >= g.N &&
+      g.c_nper >= g.N && g.M >= 1 && g.lda * 4 * 33 < (1ll << 31) && g.ldb * 4 * 33 < (1ll << 31) && g.M < (1ll << 36)) {
+    static const bool no_thin = getenv("GCT_GEMM_NO_THIN") != nullptr;     // A/B switch
+    if (!no_thin) {
+      ++g_gemm_launches[0];
+      return launch_panel<32, true>(g, st);
     }
   }
   // skinny M (decode steps): 64x64 tiles when the 128x128 grid would leave most CUs idle

@@ -666,6 +666,21 @@ def test_linear_bf16x6_small_tile_kernel(ops, M, K, nper, nseg):
         close(c[3], a[3].double(), 5e-5, 1e-4, "dropout + residual")
 
 
+@pytest.mark.parametrize("M,K,N,ldy,bias", [(512, 512, 31, 31, True), (4099, 1024, 28, 40, True), (7, 256, 1, 1, False),
+                                            (41000, 512, 30, 30, True), (33, 512, 32, 36, True)])
+def test_linear_narrow_output_panel_kernel(ops, M, K, N, ldy, bias):
+    """N <= 32 output columns (the vocabulary head, 28-31 columns; the property head, 1 column): the ragged panel
+    kernel -- any N, any leading dimension of the output, weight rows beyond N never stored.  Values vs fp64; columns
+    of the output buffer beyond N stay untouched."""
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    b = rnd(N, seed=3) if bias else None
+    y = torch.full((M, ldy), 7.0, device=DEV)
+    ops.linear_fwd(x.to(DEV), [w.to(DEV)], [b.to(DEV) if bias else None], [y], ldy)
+    ref = x.double() @ w.double().t() + (b.double() if bias else 0.0)
+    close(y[:, :N], ref, 2e-5, 2e-5, "narrow-output panel kernel")
+    assert (y[:, N:] == 7.0).all()
+
+
 def test_linear_bf16x6_split_k_over_the_whole_problem(ops):
     """Few 128x256 tiles and a long reduction (FFN-2 of a decode step with >= 1 024 rows): with a workspace the bf16x6
     kernel runs with K split into slabs + the fix-up kernel (which applies the fused epilogue).  Same dropout mask and
