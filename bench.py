@@ -239,10 +239,19 @@ def decode_block(model, a, dev, world, fence, reduce_max):
     # No collective sits inside the try: a rank that fails here still reaches the fence and the max-reduction below, so
     # a decode problem on one rank can never hang the job or cost it the headline line.
     err, dt_local, ys = None, 1e30, None                          # 1e30: "this rank failed" through the MAX reduction
+    use_graphs, probe = True, {}
     try:
         kd.start(z, src_mask, dconds, max_total_len=96)
         kd.generate(ys0, 80, use_graphs=True, check_every=0)      # warm-up + graph capture
         torch.cuda.synchronize()
+        # launch-mode probe (untimed): graph replay is normally the faster way to issue the ~70 launches of a step, but
+        # one box of round 2 replayed graphs three times slower than anything else it did; same kernels either way
+        for mode in (True, False):
+            t0 = time.perf_counter()
+            kd.generate(ys0, 17, use_graphs=mode, check_every=0)
+            torch.cuda.synchronize()
+            probe["graphs" if mode else "eager"] = round((time.perf_counter() - t0) / 16 * 1e3, 3)
+        use_graphs = probe["graphs"] <= 1.3 * probe["eager"]     # replay unless it is clearly the slower way on this box
     except Exception as exc:                                      # noqa: BLE001
         err = repr(exc)
     fence()
@@ -252,7 +261,7 @@ def decode_block(model, a, dev, world, fence, reduce_max):
             try:
                 t0 = time.perf_counter()
                 kd.start(z, src_mask, dconds, max_total_len=96)   # per-sequence set-up and the prefill are inside
-                ys = kd.generate(ys0, 80, use_graphs=True, check_every=0)
+                ys = kd.generate(ys0, 80, use_graphs=use_graphs, check_every=0)
                 torch.cuda.synchronize()
                 dt_local = time.perf_counter() - t0
             except Exception as exc:                              # noqa: BLE001
@@ -267,7 +276,7 @@ def decode_block(model, a, dev, world, fence, reduce_max):
     return {"metric": "decoded SMILES/sec (KV-cached greedy decode, max_strlen 80)", "value": round(n * world / dt, 1),
             "unit": "SMILES/s", "n_per_gpu": n, "generated_tokens": int(ys.shape[1]) - 1, "latent_len": Le,
             "ms_per_token": round(dt / 79 * 1e3, 3), "repetitions_ms": [round(r * 1e3, 1) for r in reps],
-            "graph_replay": bool(getattr(kd, "graph_replay", True)),
+            "graph_replay": bool(use_graphs and getattr(kd, "graph_replay", True)), "launch_probe_ms_per_token": probe,
             "model_type": a.model_type}
 
 
