@@ -5,7 +5,10 @@ on ys[:, :i+1] for every generated token -- fc_z(z), all six cross-attention K/V
 and every earlier position are recomputed 79 times, with one device->host sync per step.
 Because the decoder is causal, position j's hidden states depend only on tokens 0..j, so the
 same token ids come out of
-  * `start`:   z and the cross-attention K/V of all layers projected ONCE;
+  * `start`:   once per sequence, the cross-attention operands: the key / value projections of the memory fc_z(z) are
+               FOLDED into the query / output projections (`_fold_cross`), so a step attends over the latent rows z
+               themselves (gct_attn_decode_z) and no per-layer K / V of the memory is built -- or, with a latent wider
+               than 2 d_model / H or `GCT_DECODE_ZATTN=0`, the K/V of all layers projected once;
   * `prefill`: the prefix (<sos>, or <sos> scaffold <sep>; with use_cond2dec the n_c condition tokens in
                front of it, which see each other and the first token -- Model/modules.py:19-26) through ONE ordinary
                decoder forward, whose per-layer self-attention K/V fill the caches;
