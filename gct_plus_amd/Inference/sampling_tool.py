@@ -96,7 +96,8 @@ class Sampling:
         zs, ys, src_mask = zs.to(self.device), ys.to(self.device), src_mask.to(self.device)
         dconds = None if dconds is None else dconds.to(self.device)
         total = ys.size(1) + self.max_strlen
-        self.kv.start(zs, src_mask, dconds, max_total_len=min(200, total))    # the positional table has 200 rows
+        # the positional table has 200 rows, of which use_cond2dec spends n_c on the condition tokens
+        self.kv.start(zs, src_mask, dconds, max_total_len=min(200 - self.kv.off, total))
         return self.kv.generate(ys, self.max_strlen, algo=self.decode_algo, seed=self.seed,
                                 use_graphs=self.use_graphs)
 

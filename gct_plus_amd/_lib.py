@@ -28,11 +28,11 @@ SIGNATURES = {
                              I32, P, P, F32, U64, U32, P]),
     "gct_linear_fwd_ws_bytes": (I64, [I64, I32, I32]),
     "gct_linear_fwd_ws": (I32, [P, I64, I64, I32, P, P, P, I64, P, P, P, I32, I32, P, P, P, I64,
-                                I32, P, P, F32, U64, U32, P, P]),
+                                I32, P, P, F32, U64, U32, P, I64, P]),
     "gct_linear_fwd_p": (I32, [P, I64, I64, I32, P, P, P, I64, P, I64, P, P, P, I32, I32, P, P, P, I64,
-                               I32, P, P, F32, U64, U32, P, P]),
+                               I32, P, P, F32, U64, U32, P, I64, P]),
     "gct_linear_dgrad_p": (I32, [P, P, P, I64, I64, I32, I32, P, P, P, I64, P, I64, I32, P, I64, I32, P,
-                                 F32, U64, U32, P, P, I64, P]),
+                                 F32, U64, U32, P, I64, P, I64, P]),
     "gct_linear_dgrad_ws_bytes": (I64, [I64, I32, I32]),
     "gct_gemm_set_mode": (I32, [I32]),
     "gct_gemm_get_mode": (I32, []),
@@ -76,9 +76,12 @@ SIGNATURES = {
     "gct_small_linear_bwd": (I32, [P, P, P, P, I32, I32, I32, P]),
     "gct_reduce_slabs": (I32, [P, I32, I64, P, I64, I32, P]),
     "gct_add": (I32, [P, P, P, I64, P]),
+    "gct_graph_probe": (I32, [I32, I32, I32, P, P, P]),
+    "gct_device_facts": (I32, [C.c_char_p, I32]),
+    "gct_graph_census": (I32, [P, P]),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _lib = None
 
 

@@ -1329,6 +1329,9 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
       if (ns > nkt / 4) ns = nkt / 4;
       static const int ns_cap = getenv("GCT_SKINNY_SPLIT_MAX") ? atoi(getenv("GCT_SKINNY_SPLIT_MAX")) : 1 << 30;
       if (ns > ns_cap) ns = ns_cap;
+      // never more slabs than the caller's workspace holds (fewer splits, same result up to summation order)
+      const int64_t slab_b = g.M * g.N * (int64_t)sizeof(float);
+      if (slab_b > 0 && ns * slab_b > ws_bytes) ns = ws_bytes / slab_b;
       if (ns < 1) ns = 1;
     }
     if (ns <= 1) {
@@ -1425,10 +1428,11 @@ static int linear_fwd_impl(const float* x, int64_t ldx, int64_t M, int K, const 
                            const float* w1, const float* w2, int64_t ldw, const float* b0,
                            const float* b1, const float* b2, int nseg, int nper, float* y0,
                            float* y1, float* y2, int64_t ldy, int epi, const float* resid,
-                           float* pre, float p, uint64_t seed, uint32_t site, float* ws,
+                           float* pre, float p, uint64_t seed, uint32_t site, float* ws, int64_t ws_bytes,
                            void* stream, const uint16_t* wp0 = nullptr, int64_t pstride = 0) {
   GCT_CHECK_ARG(x && w0 && y0 && M >= 0 && K > 0 && nseg >= 1 && nseg <= 3 && nper > 0,
                 "linear_fwd: bad args");
+  GCT_CHECK_ARG(ws_bytes >= 0, "linear_fwd: negative workspace size");
   GCT_CHECK_ARG(nseg < 2 || (w1 && y1), "linear_fwd: missing segment 1");
   GCT_CHECK_ARG(nseg < 3 || (w2 && y2), "linear_fwd: missing segment 2");
   GCT_CHECK_ARG(epi == GCT_EPI_BIAS || nseg == 1, "linear_fwd: fused epilogues need nseg == 1");
@@ -1449,7 +1453,7 @@ static int linear_fwd_impl(const float* x, int64_t ldx, int64_t M, int K, const 
   g.bp0 = wp0; g.bp_stride = pstride;
   const bool vec = al16(x) && al16(w0) && al16(w1) && al16(w2) && (ldx % 4 == 0) &&
                    (ldw % 4 == 0) && (K % 4 == 0);
-  return launch<true, true>(g, vec, (hipStream_t)stream, ws, ws ? INT64_MAX : 0);   // ws sized by gct_linear_fwd_ws_bytes
+  return launch<true, true>(g, vec, (hipStream_t)stream, ws, ws ? ws_bytes : 0);   // every slab route checks its need against ws_bytes
 }
 
 extern "C" int gct_linear_fwd(const float* x, int64_t ldx, int64_t M, int K, const float* w0,
@@ -1458,7 +1462,7 @@ extern "C" int gct_linear_fwd(const float* x, int64_t ldx, int64_t M, int K, con
                               float* y1, float* y2, int64_t ldy, int epi, const float* resid,
                               float* pre, float p, uint64_t seed, uint32_t site, void* stream) {
   return linear_fwd_impl(x, ldx, M, K, w0, w1, w2, ldw, b0, b1, b2, nseg, nper, y0, y1, y2, ldy, epi,
-                         resid, pre, p, seed, site, nullptr, stream);
+                         resid, pre, p, seed, site, nullptr, 0, stream);
 }
 
 extern "C" int gct_linear_fwd_ws(const float* x, int64_t ldx, int64_t M, int K, const float* w0,
@@ -1466,9 +1470,9 @@ extern "C" int gct_linear_fwd_ws(const float* x, int64_t ldx, int64_t M, int K, 
                                  const float* b1, const float* b2, int nseg, int nper, float* y0,
                                  float* y1, float* y2, int64_t ldy, int epi, const float* resid,
                                  float* pre, float p, uint64_t seed, uint32_t site, float* ws,
-                                 void* stream) {
+                                 int64_t ws_bytes, void* stream) {
   return linear_fwd_impl(x, ldx, M, K, w0, w1, w2, ldw, b0, b1, b2, nseg, nper, y0, y1, y2, ldy, epi,
-                         resid, pre, p, seed, site, ws, stream);
+                         resid, pre, p, seed, site, ws, ws_bytes, stream);
 }
 
 extern "C" int gct_linear_fwd_p(const float* x, int64_t ldx, int64_t M, int K, const float* w0,
@@ -1476,9 +1480,9 @@ extern "C" int gct_linear_fwd_p(const float* x, int64_t ldx, int64_t M, int K, c
                                 int64_t plane_stride, const float* b0, const float* b1,
                                 const float* b2, int nseg, int nper, float* y0, float* y1, float* y2,
                                 int64_t ldy, int epi, const float* resid, float* pre, float p,
-                                uint64_t seed, uint32_t site, float* ws, void* stream) {
+                                uint64_t seed, uint32_t site, float* ws, int64_t ws_bytes, void* stream) {
   return linear_fwd_impl(x, ldx, M, K, w0, w1, w2, ldw, b0, b1, b2, nseg, nper, y0, y1, y2, ldy, epi,
-                         resid, pre, p, seed, site, ws, stream, wp0, plane_stride);
+                         resid, pre, p, seed, site, ws, ws_bytes, stream, wp0, plane_stride);
 }
 
 extern "C" int gct_gemm_set_mode(int mode) {
@@ -1534,7 +1538,7 @@ static int linear_dgrad_impl(const float* dy0, const float* dy1, const float* dy
                              int64_t M, int nseg, int nper, const float* w0, const float* w1,
                              const float* w2, int64_t ldw, int K, float* dx, int64_t lddx,
                              int depi, const float* pre, float p, uint64_t seed, uint32_t site,
-                             void* stream, const uint16_t* wp0, int64_t pstride, float* ws,
+                             void* stream, const uint16_t* wp0, int64_t pstride, float* ws, int64_t ws_bytes,
                              const int32_t* quad_map = nullptr, int64_t pre_rows = 0) {
   GCT_CHECK_ARG(dy0 && w0 && dx && M >= 0 && K > 0 && nseg >= 1 && nseg <= 3 && nper > 0,
                 "linear_dgrad: bad args");
@@ -1556,7 +1560,7 @@ static int linear_dgrad_impl(const float* dy0, const float* dy1, const float* dy
   g.pre_rows = quad_map ? pre_rows : 0;
   const bool vec = al16(dy0) && al16(dy1) && al16(dy2) && al16(w0) && al16(w1) && al16(w2) &&
                    (lddy % 4 == 0) && (ldw % 4 == 0) && (nper % 4 == 0) && (K % 4 == 0);
-  return launch<true, false>(g, vec, (hipStream_t)stream, ws, ws ? INT64_MAX : 0);   // ws sized by gct_linear_dgrad_ws_bytes
+  return launch<true, false>(g, vec, (hipStream_t)stream, ws, ws ? ws_bytes : 0);
 }
 
 extern "C" int gct_linear_dgrad(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
@@ -1565,7 +1569,7 @@ extern "C" int gct_linear_dgrad(const float* dy0, const float* dy1, const float*
                                 int depi, const float* pre, float p, uint64_t seed, uint32_t site,
                                 void* stream) {
   return linear_dgrad_impl(dy0, dy1, dy2, lddy, M, nseg, nper, w0, w1, w2, ldw, K, dx, lddx, depi, pre,
-                           p, seed, site, stream, nullptr, 0, nullptr);
+                           p, seed, site, stream, nullptr, 0, nullptr, 0);
 }
 
 extern "C" int gct_linear_dgrad_p(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
@@ -1573,9 +1577,11 @@ extern "C" int gct_linear_dgrad_p(const float* dy0, const float* dy1, const floa
                                   const float* w2, int64_t ldw, const uint16_t* wp0,
                                   int64_t plane_stride, int K, float* dx, int64_t lddx, int depi,
                                   const float* pre, float p, uint64_t seed, uint32_t site,
-                                  float* ws, const int32_t* quad_map, int64_t pre_rows, void* stream) {
+                                  float* ws, int64_t ws_bytes, const int32_t* quad_map, int64_t pre_rows,
+                                  void* stream) {
+  GCT_CHECK_ARG(ws_bytes >= 0, "linear_dgrad: negative workspace size");
   return linear_dgrad_impl(dy0, dy1, dy2, lddy, M, nseg, nper, w0, w1, w2, ldw, K, dx, lddx, depi, pre,
-                           p, seed, site, stream, wp0, plane_stride, ws, quad_map, pre_rows);
+                           p, seed, site, stream, wp0, plane_stride, ws, ws_bytes, quad_map, pre_rows);
 }
 
 static int linear_wgrad_impl(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,

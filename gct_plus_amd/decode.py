@@ -39,6 +39,10 @@ SKINNY_BELOW = int(os.environ.get("GCT_DECODE_SKINNY_BELOW", "1024"))
 # cross-attention of a step over the latent rows themselves (gct_attn_decode_z) instead of per-layer K / V projections of
 # the memory; `GCT_DECODE_ZATTN=0` keeps the projected K / V (the A/B switch; also taken when the latent is too wide)
 ZATTN = os.environ.get("GCT_DECODE_ZATTN", "1") != "0"
+# replay guard of use_graphs=True (KVDecoder._replay_is_fast): replay must not be slower than REPLAY_SLOW_FACTOR x the
+# eager launches of the same step on this box; `GCT_DECODE_GRAPH_GUARD=0` switches the guard off (always replay)
+REPLAY_GUARD = os.environ.get("GCT_DECODE_GRAPH_GUARD", "1") != "0"
+REPLAY_SLOW_FACTOR = 1.3
 
 
 class KVDecoder:
@@ -53,6 +57,7 @@ class KVDecoder:
         self.off = dec.nconds if self.c2d else 0          # cache / positional index of token 0
         self.graphs = {}
         self.graph_replay = True
+        self.replay_probe = None                          # numbers of the replay guard (after the first capture)
         self._shape = None
 
     # -------------------------------------------------------------------------------------
@@ -87,6 +92,11 @@ class KVDecoder:
         T = int(max_total_len) + self.off              # cache rows: condition tokens (cond2dec) + tokens
         if T > 256 or Lk > 256:
             raise ValueError("decode lengths above 256 are not supported by gct_attn_decode")
+        pe_rows = dec.pe.pe.shape[1]
+        if T > pe_rows:
+            # the positional table has pe_rows rows (Model/modules.py:116-144: 200); the reference fails loudly past it
+            raise ValueError(f"decode: {max_total_len} tokens + {self.off} condition rows exceed the {pe_rows}-row "
+                             "positional table")
         shape = (n, Lk, T, str(dev), self.zattn, lat)
         if shape != self._shape:
             # new geometry: new buffers, and the graphs captured against the old ones are dropped with them
@@ -122,9 +132,11 @@ class KVDecoder:
             self.seed = torch.zeros(1, dtype=torch.int64, device=dev)      # multinomial seed of this generate()
             dff = dec.layers[0].ff.linear_1.weight.shape[0]
             V = self.model.out.weight.shape[0]
-            wsb = max(ops._L().gct_linear_fwd_ws_bytes(n, dff, d), ops._L().gct_linear_fwd_ws_bytes(n, d, 3 * d),
-                      ops._L().gct_linear_fwd_ws_bytes(n, d, dff), ops._L().gct_linear_fwd_ws_bytes(n, d, d),
-                      ops._L().gct_linear_fwd_ws_bytes(n, d, V))
+            need = ops._L().gct_linear_fwd_ws_bytes
+            shapes = [(dff, d), (d, 3 * d), (d, dff), (d, d), (d, V)]           # (K, N) of every GEMM of a step
+            if self.zattn:
+                shapes += [(d, self.nq), (self.nq, d)]                         # the folded cross-attention projections
+            wsb = max(need(n, k_, n_) for k_, n_ in shapes)
             self.ws = torch.empty(wsb // 4 + 64, device=dev)           # split-K / tail slabs of the step's GEMMs
             # few rows: the skinny split-K kernels; many rows (n >= 1024): the general path, i.e. the bf16x6 kernels
             self.gemm_kw = dict(splitk_ws=self.ws) if n < SKINNY_BELOW else dict(ws=self.ws)
@@ -314,42 +326,105 @@ class KVDecoder:
             self._select(mode)
             return
         g = self.graphs.get(mode)
-        if g is False:                                  # capture failed earlier for these buffers: stay eager
-            self.step()
+        if g is False:                                  # no usable graph for these buffers (capture failed, or replay is
+            self.step()                                 # the slower launch mode on this box): same kernels, eagerly
             self._select(mode)
             return
         if g is None:
-            # Warm-up run on a side stream (lazy LDS opt-ins, allocator), then capture.  The warm-up really executes a
-            # step (it advances the device position and writes a token), so the state it touches is restored before
-            # the capture; a capture itself executes nothing.
-            keep = (self.pos.clone(), self.ys.clone(), self.valid.clone(), self.done.clone())
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                self.step()
-                self._select(mode)
-            torch.cuda.current_stream().wait_stream(s)
-            # (the key / value row the warm-up appended is rewritten with the same values by the replay below)
-            self.pos.copy_(keep[0]); self.ys.copy_(keep[1]); self.valid.copy_(keep[2]); self.done.copy_(keep[3])
-            g = torch.cuda.CUDAGraph()
-            try:
-                # thread_local: another thread's runtime calls (the RCCL watchdog of a data-parallel job queries
-                # events) must not invalidate this thread's capture
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self.step()
-                    self._select(mode)
-            except RuntimeError as exc:                 # no graph for these buffers: same kernels, launched eagerly
-                import warnings
-                warnings.warn(f"KVDecoder: graph capture failed ({exc}); decoding without graph replay")
-                torch.cuda.synchronize()
-                self.pos.copy_(keep[0]); self.ys.copy_(keep[1]); self.valid.copy_(keep[2]); self.done.copy_(keep[3])
-                self.graphs[mode] = False
-                self.graph_replay = False
-                self.step()
-                self._select(mode)
-                return
-            self.graphs[mode] = g
+            g = self._capture(mode)
+            if g is None:
+                return                                  # _capture ran the step eagerly
         g.replay()
+
+    def _state(self):
+        return (self.pos.clone(), self.ys.clone(), self.valid.clone(), self.done.clone())
+
+    def _restore(self, keep):
+        self.pos.copy_(keep[0]); self.ys.copy_(keep[1]); self.valid.copy_(keep[2]); self.done.copy_(keep[3])
+
+    def _capture(self, mode):
+        """Capture step + select into one graph; returns it, or None after running the step eagerly (capture failed, or
+        the replay guard found replay slower than eager launches on this box)."""
+        # Warm-up run on a side stream (lazy LDS opt-ins, allocator), then capture.  The warm-up really executes a
+        # step (it advances the device position and writes a token), so the state it touches is restored before
+        # the capture; a capture itself executes nothing.
+        keep = self._state()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.step()
+            self._select(mode)
+        torch.cuda.current_stream().wait_stream(s)
+        # (the key / value row the warm-up appended is rewritten with the same values by the replay below)
+        self._restore(keep)
+        try:
+            g = torch.cuda.CUDAGraph(keep_graph=True)   # the hipGraph_t stays readable (graphdiag.census)
+        except TypeError:
+            g = torch.cuda.CUDAGraph()
+        try:
+            # thread_local: another thread's runtime calls (the RCCL watchdog of a data-parallel job queries
+            # events) must not invalidate this thread's capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self.step()
+                self._select(mode)
+        except RuntimeError as exc:                     # no graph for these buffers: same kernels, launched eagerly
+            import warnings
+            warnings.warn(f"KVDecoder: graph capture failed ({exc}); decoding without graph replay")
+            torch.cuda.synchronize()
+            self._restore(keep)
+            self.graphs[mode] = False
+            self.graph_replay = False
+            self.step()
+            self._select(mode)
+            return None
+        self.graphs[mode] = g
+        if REPLAY_GUARD and not self._replay_is_fast(mode, g, keep):
+            self.graphs[mode] = False
+            self.graph_replay = False
+            self.step()
+            self._select(mode)
+            return None
+        return g
+
+    def _replay_is_fast(self, mode, g, keep):
+        """Replay guard: a few steps launched eagerly and a few replayed, timed on the device, state restored after
+        each.  Replay is the faster way to issue the ~70 launches of a step everywhere it behaves; on boxes where it is
+        clearly the slower one (round 2: 3-13x) the decoder keeps launching eagerly, says so once, and leaves the
+        numbers and the graph's census in `self.replay_probe` for the caller (bench.py prints them)."""
+        room = self.T - self.off - (int(keep[0].item()) + 1) - 1         # steps the caches still have room for
+        k = min(4, room)
+        if k < 1:
+            return True
+
+        def timed(fn):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(k):
+                fn()
+            e1.record()
+            e1.synchronize()
+            self._restore(keep)
+            return e0.elapsed_time(e1) / k
+
+        def eager():
+            self.step()
+            self._select(mode)
+
+        g.replay()                                                       # first replay (instantiation, upload): untimed
+        self._restore(keep)
+        t_graph = min(timed(g.replay), timed(g.replay))
+        t_eager = min(timed(eager), timed(eager))
+        torch.cuda.synchronize()
+        from . import graphdiag
+        self.replay_probe = {"ms_per_step_graph": round(t_graph, 4), "ms_per_step_eager": round(t_eager, 4),
+                             "steps_timed": k, "rows": self.n, "census": graphdiag.census(g)}
+        if t_graph <= REPLAY_SLOW_FACTOR * t_eager:
+            return True
+        import warnings
+        warnings.warn(f"KVDecoder: replaying the captured step takes {t_graph:.3f} ms against {t_eager:.3f} ms for the "
+                      f"same kernels launched eagerly on this box; decoding with eager launches "
+                      f"(GCT_DECODE_GRAPH_GUARD=0 forces replay; python tools/graph_probe.py prints the diagnosis)")
+        return False
 
 
 @torch.no_grad()

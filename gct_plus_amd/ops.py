@@ -288,21 +288,24 @@ def linear_fwd(x2d, ws_: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Ten
     w = _seg3(ws_)
     b = _seg3(bs)
     y = _seg3(outs)
+    need = _ws_need("gct_linear_fwd_ws_bytes", M, K, nper * len(ws_))     # skinny split-K slabs or bf16x6 tail slabs
+    for t in (splitk_ws, ws):
+        if t is not None and t.numel() * 4 < need:
+            raise _lib.GctError(f"linear_fwd: workspace of {t.numel() * 4} B < {need} B "
+                                f"(gct_linear_fwd_ws_bytes({M}, {K}, {nper * len(ws_)}))")
     if splitk_ws is not None:      # skinny-M path (decode): split-K through the workspace
         check(_L().gct_linear_fwd_ws(_p(x2d), x2d.stride(0), M, K, w[0], w[1], w[2], ws_[0].stride(0),
                                      b[0], b[1], b[2], len(ws_), nper, y[0], y[1], y[2], ldy, epi,
-                                     _p(resid), _p(pre), p, seed, site, _p(splitk_ws), _st()),
+                                     _p(resid), _p(pre), p, seed, site, _p(splitk_ws), splitk_ws.numel() * 4, _st()),
               "gct_linear_fwd_ws")
         return
     wp, pstride = _plane_ptr(ws_)
-    need = _ws_need("gct_linear_fwd_ws_bytes", M, K, nper * len(ws_))     # skinny split-K slabs or bf16x6 tail slabs
-    if ws is not None and ws.numel() * 4 < need:
-        raise _lib.GctError(f"linear_fwd: workspace of {ws.numel() * 4} B < {need} B")
     wsb = ws if ws is not None else (workspace(need, x2d.device) if need > 256 else None)
     with _Timed("gemm_fwd", 2.0 * M * K * nper * len(ws_)):
         check(_L().gct_linear_fwd_p(_p(x2d), x2d.stride(0), M, K, w[0], w[1], w[2], ws_[0].stride(0),
                                     wp, pstride, b[0], b[1], b[2], len(ws_), nper, y[0], y[1], y[2],
-                                    ldy, epi, _p(resid), _p(pre), p, seed, site, _p(wsb), _st()),
+                                    ldy, epi, _p(resid), _p(pre), p, seed, site, _p(wsb),
+                                    0 if wsb is None else wsb.numel() * 4, _st()),
               "gct_linear_fwd_p")
 
 
@@ -318,7 +321,7 @@ def linear_dgrad(dys: Sequence[torch.Tensor], lddy: int, M: int, ws_: Sequence[t
         wsb = workspace(need, dx.device) if need > 256 else None
         check(_L().gct_linear_dgrad_p(d[0], d[1], d[2], lddy, M, len(ws_), nper, w[0], w[1], w[2],
                                       ws_[0].stride(0), wp, pstride, K, _p(dx), dx.stride(0), depi,
-                                      _p(pre), p, seed, site, _p(wsb),
+                                      _p(pre), p, seed, site, _p(wsb), 0 if wsb is None else wsb.numel() * 4,
                                       None if live is None else _p(live.quad_list),
                                       pre.shape[0] if (live is not None and pre is not None and pre_full) else 0,
                                       _st()), "gct_linear_dgrad_p")
@@ -546,14 +549,15 @@ _ATTN_BWD_WS = {}
 
 
 def _attn_bwd_ws(dev, nbytes):
-    """Scratch of the two-launch attention backward: one buffer per device, grown on demand (launches on one
-    stream are ordered, so consecutive calls may share it)."""
+    """Scratch of the two-launch attention backward: one buffer per (device, stream) like `workspace`, grown on demand
+    (launches on one stream are ordered, so consecutive calls may share it; two streams never share one)."""
     if nbytes <= 0:
         return None
-    ws = _ATTN_BWD_WS.get(dev)
+    key = (dev, _st())
+    ws = _ATTN_BWD_WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _ATTN_BWD_WS[dev] = ws
+        _ATTN_BWD_WS[key] = ws
     return ws
 
 

@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 PAD_ID, SOS_ID, EOS_ID = 1, 2, 3
+SEP_ID = 4                # <sep> of the TRG_sep field (specials order unk, pad, sos, eos, sep); 2 in SRC_sep
 N_SYMBOLS = 26
 
 

@@ -37,7 +37,7 @@ extern "C" {
 #define GCT_ERR_ARG (-1)  /* bad shape / alignment / null pointer            */
 #define GCT_ERR_HIP (-2)  /* a HIP runtime call failed (launch error)        */
 
-#define GCT_ABI_VERSION 8
+#define GCT_ABI_VERSION 9
 
 int gct_version(void);
 const char* gct_last_error(void);
@@ -106,7 +106,9 @@ int gct_linear_fwd_ws(const float* x, int64_t ldx, int64_t M, int K,
                       const float* b0, const float* b1, const float* b2, int nseg, int nper,
                       float* y0, float* y1, float* y2, int64_t ldy,
                       int epi, const float* resid, float* pre, float p, uint64_t seed, uint32_t site,
-                      float* ws, void* stream);
+                      float* ws, int64_t ws_bytes, void* stream);
+/* ws_bytes: size of ws.  A route that needs more slabs than ws holds takes fewer K-splits (same result up to the
+ * fp32 summation order) or no workspace route at all; nothing is ever written past ws + ws_bytes. */
 
 /* dx[m][k] (op)= sum_s sum_n dy_s[m][n] * w_s[n][k]
  *   GCT_DEPI_STORE / GCT_DEPI_ACCUM (dx += ...) /
@@ -162,13 +164,14 @@ int gct_linear_fwd_p(const float* x, int64_t ldx, int64_t M, int K,
                      const float* b0, const float* b1, const float* b2,
                      int nseg, int nper, float* y0, float* y1, float* y2, int64_t ldy,
                      int epi, const float* resid, float* pre, float p, uint64_t seed, uint32_t site,
-                     float* ws, void* stream);
+                     float* ws, int64_t ws_bytes, void* stream);
 int gct_linear_dgrad_p(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
                        int64_t M, int nseg, int nper,
                        const float* w0, const float* w1, const float* w2, int64_t ldw,
                        const uint16_t* wp0, int64_t plane_stride, int K,
                        float* dx, int64_t lddx, int depi, const float* pre, float p, uint64_t seed,
-                       uint32_t site, float* ws, const int32_t* quad_map, int64_t pre_rows, void* stream);
+                       uint32_t site, float* ws, int64_t ws_bytes, const int32_t* quad_map, int64_t pre_rows,
+                       void* stream);
 /* quad_map (nullable): the M rows are quad-compacted (gct_live_rows); GCT_DEPI_GELU_BWD then regenerates the dropout
  * mask of compact quad q from original quad quad_map[q].  pre_rows == 0: pre is compact like dy / dx; pre_rows > 0:
  * pre keeps the forward's row space (pre_rows rows) and is read through the quad map (no gathered copy needed). */
@@ -380,6 +383,21 @@ int gct_reduce_slabs(const float* slabs, int nslab, int64_t stride, float* dst, 
                      int accumulate, void* stream);
 /* y = a + b (gradient joins of the residual stream) */
 int gct_add(const float* a, const float* b, float* y, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------ hipGraph replay diagnostics (csrc/graphprobe.hip)
+ * BASELINE configs[4] asks for a hipGraph-captured decode step (reference loop: Inference/sampling_tool.py:140-184).
+ * Some boxes replay graphs far slower than they launch the same kernels one by one; these calls tell a caller what
+ * the box does before it trusts a replay.
+ * gct_graph_probe: `nodes` launches of a do-nothing kernel chained on a private stream, timed as `reps` eager passes
+ *   and as `reps` replays of the captured chain (ms per pass).  variant 0: 8-byte kernarg, one workgroup; 1: a 320-byte
+ *   by-value argument block read by every wave of a 2048 x 512 grid; 2: as 1 with 144 KB of dynamic LDS; 3: as 1 with
+ *   the block behind one pointer into device memory.  Synchronises its own stream only.
+ * gct_device_facts: runtime / driver version, large-BAR and host-access attributes ... as one JSON object.
+ * gct_graph_census: node counts of a captured hipGraph_t; out8 = {nodes, kernels, memcpys, memsets, others,
+ *   max dynamic LDS bytes, max grid blocks, kernels with more than 64 KB of LDS}. */
+int gct_graph_probe(int variant, int nodes, int reps, float* eager_ms, float* graph_ms, int32_t* graph_nodes);
+int gct_device_facts(char* buf, int cap);
+int gct_graph_census(void* hip_graph, int64_t* out8);
 
 #ifdef __cplusplus
 }

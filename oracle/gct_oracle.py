@@ -473,13 +473,17 @@ def make_adam(params, lr=1e-4, b1=0.9, b2=0.98, eps=1e-9):
 # greedy decode (Inference/sampling_tool.py:140-184), restated loop around decode()
 # --------------------------------------------------------------------------------------
 @torch.no_grad()
-def greedy_decode(P, cfg, z, src_mask, dconds, sos_id, eos_id, pad_id, max_strlen=80):
+def greedy_decode(P, cfg, z, src_mask, dconds, sos_id, eos_id, pad_id, max_strlen=80, ys0=None, trace=None):
+    """ys0: the prefix the scaffold samplers start from (<sos> scaffold <sep>, sampling_tool.py:452-498) instead of the
+    single <sos> column; trace (a list): receives the logits of the last position of every step (tie diagnostics)."""
     n = z.size(0)
-    ys = torch.full((n, 1), sos_id, dtype=torch.long)
+    ys = torch.full((n, 1), sos_id, dtype=torch.long) if ys0 is None else ys0.clone()
     done = torch.zeros(n, dtype=torch.bool)
     for i in range(max_strlen - 1):
         trg_mask = get_trg_mask(ys, pad_id, cfg["use_cond2dec"], dconds if cfg["nconds"] > 0 else None)
         logits = decode(P, cfg, ys, z, src_mask, trg_mask, dconds)
+        if trace is not None:
+            trace.append(logits[:, -1].clone())
         nxt = F.softmax(logits, dim=-1)[:, -1].argmax(dim=-1)
         ys = torch.cat([ys, nxt.unsqueeze(1)], dim=1)
         done |= nxt == eos_id

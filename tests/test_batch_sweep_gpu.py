@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
 
 
-@pytest.mark.parametrize("mtype,B", [("vaetf", 24), ("vaetf", 128), ("pscavaetf", 200)])
+@pytest.mark.parametrize("mtype,B", [("vaetf", 24), ("vaetf", 128), ("pscavaetf", 200), ("vaetf", 512), ("pvaetf", 512)])
 def test_shortcuts_agree_with_plain_path(mtype, B):
     import batch_sweep
     rel, on, off = batch_sweep.compare(mtype, B)

@@ -62,6 +62,44 @@ def test_kv_decode_matches_uncached_full_size(mtype, graphs):
     assert torch.equal(ys, ref)
 
 
+@pytest.mark.parametrize("graphs", [False, True])
+def test_kv_decode_full_size_pscavaetf_vs_oracle_loop(graphs):
+    """BASELINE configs[4]'s model type at full size against the ORACLE's restated loop (the un-cached CPU decoder of
+    Inference/sampling_tool.py:140-184 with the scaffold prefix of :452-498), not only against the un-cached HIP loop:
+    n = 4, 79 generated tokens, no early stop.  Ids must be equal; where they are not, the oracle's two best logits at
+    the first differing step must be an fp32 tie (gap < 1e-4 at a logit scale of ~5) -- both sides take the argmax of
+    fp32 logits accumulated in different orders."""
+    from oracle import gct_oracle as O
+    from gct_plus_amd.decode import KVDecoder
+    mtype = "pscavaetf"
+    model = build(mtype, full=True, seed=3)
+    vs, vt = synthetic.vocab_sizes(mtype)
+    nc = synthetic.n_conds(mtype)
+    n, Le = 4, 40 + nc
+    g = torch.Generator().manual_seed(31)
+    z = torch.randn(n, Le, 128, generator=g)
+    dconds = torch.randn(n, nc, generator=g)
+    src_mask = torch.ones(n, 1, Le, dtype=torch.bool)
+    pre = torch.randint(5, 30, (n, 6), generator=g)
+    ys0 = torch.cat([torch.full((n, 1), synthetic.SOS_ID), pre, torch.full((n, 1), 4)], 1)
+    cfg = O.make_cfg(mtype, vs, vt, dropout=0.0, nconds=nc, use_cond2lat=True)
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    trace = []
+    ref = O.greedy_decode(P, cfg, z, src_mask, dconds, synthetic.SOS_ID, -1, synthetic.PAD_ID, max_strlen=80,
+                          ys0=ys0, trace=trace)
+    kd = KVDecoder(model, synthetic.PAD_ID, synthetic.SOS_ID, eos_id=-1)
+    kd.start(z.cuda(), src_mask.cuda(), dconds.cuda(), max_total_len=96)
+    ys = kd.generate(ys0.cuda(), max_strlen=80, use_graphs=graphs, check_every=0).cpu()
+    assert ys.shape == ref.shape == (n, ys0.shape[1] + 79)
+    for b in range(n):
+        diff = (ys[b] != ref[b]).nonzero()
+        if diff.numel() == 0:
+            continue
+        t = int(diff[0]) - ys0.shape[1]                 # first differing generated token of this sample
+        top2 = trace[t][b].topk(2).values
+        assert float(top2[0] - top2[1]) < 1e-4, (b, t, top2.tolist(), ys[b].tolist(), ref[b].tolist())
+
+
 def test_multinomial_matches_probabilities():
     """Sampling cannot share an RNG stream with torch.multinomial; compare at the probability
     level: empirical frequencies of the first sampled token vs softmax(logits)."""
