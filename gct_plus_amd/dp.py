@@ -4,13 +4,18 @@ xGMI (torch.distributed backend "nccl" IS RCCL on ROCm).
 Replaces torch.nn.parallel.DistributedDataParallel at train1.py:111-112 of the reference:
   * construction broadcasts the flat parameter buffer from rank 0 (DDP ctor semantics);
   * the model's flat gradient buffer (one contiguous 178 MB range, see flat.py) is split into
-    a few contiguous BUCKETS along trunk boundaries (encoder | decoder+heads).  A bucket's
-    averaged all-reduce (ReduceOp.AVG: DDP's mean-of-per-rank-sum-loss gradients, SURVEY.md
-    2.3) is launched from post-accumulate-grad hooks the moment its last gradient has been
-    written -- the decoder-side exchange (57 % of the bytes) runs on RCCL's stream while the
-    encoder trunk is still in its backward pass; whatever is left is launched, and everything
-    is waited for, in an end-of-backward callback.  Large contiguous messages, no bucket
-    copies (DDP's 25 MB buckets copy every gradient twice);
+    contiguous BUCKETS, one per encoder / decoder LAYER (12.6 / 16.8 MB each) plus the small
+    runs between them (embeddings, final norms, fc_z, sampler, out; runs under 2 MB join the
+    bucket that follows them in the buffer).  A bucket's averaged all-reduce (ReduceOp.AVG:
+    DDP's mean-of-per-rank-sum-loss gradients) is launched the moment its last
+    gradient has been written: the trunk backward passes (engine.encoder_trunk_bwd /
+    decoder_trunk_bwd, each ONE autograd Function) report every finished layer through
+    engine.GRAD_NOTIFY -- post-accumulate-grad hooks cannot see inside a trunk, they only
+    fire when the whole trunk returns -- so layer l's exchange runs on RCCL's stream while
+    layer l-1 is still in its backward pass and only the first encoder layer's 12.6 MB (plus
+    the embedding) is exposed at the end; whatever is left is launched, and everything is
+    waited for, in an end-of-backward callback.  Contiguous messages, no bucket copies (DDP's
+    25 MB buckets copy every gradient twice);
   * the `pe` buffers are constants, so DDP's per-forward buffer broadcast is dropped;
   * parameters that receive no gradient (Vaetf's dead encoder.fc_*, learned after the first
     backward) contribute zeros instead of tripping DDP's unused-parameter check.
@@ -64,21 +69,39 @@ class FlatDataParallel(nn.Module):
             self._make_buckets()
 
     # ------------------------------------------------------------------ bucket bookkeeping
+    MIN_BUCKET_BYTES = 2 << 20          # smaller runs of the flat buffer join the run that follows them
+
     def _make_buckets(self):
+        import re
         flat = self.module._gct_flat
         order, offs, total = flat["order"], flat["offsets"], flat["numel"]
         names = {id(p): n for n, p in self.module.named_parameters()}
-        groups = []                                   # contiguous runs by top-level sub-module
+        layer_re = re.compile(r"^(encoder|decoder)\.layers\.(\d+)\.")
+        groups = []                                   # contiguous runs: one per trunk layer, one per stretch between
         for p, o in zip(order, offs):
-            top = "encoder" if names[id(p)].startswith("encoder.") else "rest"
-            if not groups or groups[-1]["top"] != top:
-                groups.append({"top": top, "start": o, "params": []})
+            m = layer_re.match(names[id(p)])
+            key = m.group(0) if m else names[id(p)].split(".", 1)[0]
+            if not groups or groups[-1]["top"] != key:
+                groups.append({"top": key, "start": o, "params": []})
             groups[-1]["params"].append(p)
         for i, g in enumerate(groups):
             g["end"] = groups[i + 1]["start"] if i + 1 < len(groups) else total
-        self._buckets = groups
+        merged = []                                   # a tiny run is exchanged together with its successor
+        carry = None
+        for g in groups:
+            if carry is not None:
+                g = {"top": carry["top"] + "+" + g["top"], "start": carry["start"], "end": g["end"],
+                     "params": carry["params"] + g["params"]}
+                carry = None
+            if (g["end"] - g["start"]) * 4 < self.MIN_BUCKET_BYTES and g is not groups[-1] and g["end"] < total:
+                carry = g
+            else:
+                merged.append(g)
+        if carry is not None:
+            merged.append(carry)
+        self._buckets = merged
         self._bucket_of = {}
-        for bi, g in enumerate(groups):
+        for bi, g in enumerate(merged):
             for p in g["params"]:
                 self._bucket_of[id(p)] = bi
                 if self.overlap and p.requires_grad:
@@ -91,6 +114,7 @@ class FlatDataParallel(nn.Module):
         self._fired = set()
         self._works = []
         self._launched = [False] * len(self._buckets)
+        self._late = [False] * len(self._buckets)     # a gradient of the bucket did not land in its flat slot yet
         self._left = [sum(1 for p in g["params"] if p.requires_grad and id(p) not in self._dead)
                       for g in self._buckets]
 
@@ -100,15 +124,35 @@ class FlatDataParallel(nn.Module):
         self._fired.add(id(p))
         bi = self._bucket_of[id(p)]
         self._left[bi] -= 1
-        if self._left[bi] == 0 and self._learned and not self._launched[bi]:
+        if self._left[bi] == 0 and self._learned and not self._launched[bi] and not self._late[bi]:
             self._launch(bi)
+
+    def _notify(self, params, grads):
+        """engine.GRAD_NOTIFY: the trunk backward has finished these parameters' gradients (grads[i] is the tensor
+        the kernels wrote: the flat slot itself, or a temporary that autograd will accumulate later -- then the bucket
+        waits for the end of the backward pass like before)."""
+        if not self._armed or not self.overlap:
+            return
+        for p, gt in zip(params, grads):
+            bi = self._bucket_of.get(id(p))
+            if bi is None or not p.requires_grad:
+                continue
+            v = getattr(p, "_gct_gview", None)
+            if gt is None or v is None or gt.data_ptr() != v.data_ptr():
+                self._late[bi] = True                  # not in its slot: exchanged from _finalize
+        for p in params:
+            if id(p) in self._bucket_of:
+                self._on_grad(p)
 
     @torch.no_grad()
     def _launch(self, bi):
         g = self._buckets[bi]
         for p in g["params"]:                          # stray / missing gradients -> flat slots
             if p.grad is None:
-                p._gct_gview.zero_()
+                # no .grad yet: either a parameter that never gets one (zero contribution), or a gradient the trunk
+                # backward has already written into its flat slot and reported (autograd adopts the view afterwards)
+                if id(p) not in self._fired:
+                    p._gct_gview.zero_()
             elif p.grad.data_ptr() != p._gct_gview.data_ptr():
                 p._gct_gview.copy_(p.grad)
                 p.grad = p._gct_gview
@@ -133,6 +177,8 @@ class FlatDataParallel(nn.Module):
             self._armed = True
             if self._flat_ok:
                 self._reset_round()
+                from . import engine
+                engine.GRAD_NOTIFY = self._notify          # finished layers report from inside the trunk backward
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
         return grad
 
@@ -140,6 +186,10 @@ class FlatDataParallel(nn.Module):
     def _finalize(self):
         self._armed = False
         m = self.module
+        if self._flat_ok:
+            from . import engine
+            if engine.GRAD_NOTIFY == self._notify:
+                engine.GRAD_NOTIFY = None
         if self._flat_ok:
             if not self._learned:                      # first backward: learn the dead set
                 self._dead = {id(p) for g in self._buckets for p in g["params"]

@@ -34,6 +34,19 @@ COMPACT_MAX_FRACTION = 0.85
 COMPACT_KV = os.environ.get("GCT_COMPACT_KV", "1") != "0"
 
 
+# Data parallelism (dp.FlatDataParallel) sets this while a backward pass is running: called as
+# GRAD_NOTIFY(params, grads) when a trunk backward has finished writing the gradients of a layer, so that the layer's
+# bucket of the flat gradient buffer can be exchanged while the layers underneath are still in their backward pass
+# (autograd's post-accumulate hooks only fire when the whole trunk Function returns).
+GRAD_NOTIFY = None
+
+
+def _grads_done(module, G: "GradSink"):
+    if GRAD_NOTIFY is not None:
+        ps = list(module.parameters())
+        GRAD_NOTIFY(ps, [G.out.get(p) for p in ps])
+
+
 def next_seed() -> int:
     """Fresh 64-bit dropout/eps seed per trunk call, derived from torch.manual_seed()."""
     if _SEED["base"] != torch.initial_seed():
@@ -265,6 +278,7 @@ def enc_layer_bwd(run: Run, layer, saved, g, G: GradSink, gd=None, gdbuf=None, b
     dr = _ffn_drop(run, below, gdbuf)
     ops.norm_bwd(g, x_in, layer.norm_1.alpha, m1, r1, G(layer.norm_1.alpha), G(layer.norm_1.bias),
                  out=g, eps=layer.norm_1.eps, drop=dr)
+    _grads_done(layer, G)
     return g, (None if dr is None else gdbuf)
 
 
@@ -296,6 +310,7 @@ def dec_layer_bwd(run: Run, layer, saved, g, de, first_de, G: GradSink, live=Non
     dr = _ffn_drop(run, below, gdbuf)
     ops.norm_bwd(t, x, layer.norm_1.alpha, m1, r1, G(layer.norm_1.alpha), G(layer.norm_1.bias),
                  dres=g, out=g, eps=layer.norm_1.eps, live=live, drop=dr)
+    _grads_done(layer, G)
     return g, (None if dr is None else gdbuf)
 
 

@@ -99,13 +99,19 @@ def main(rank, world_size, argv=None):
     train_opts(parser)
     args = parser.parse_args(argv)
     local = int(os.environ.get("LOCAL_RANK", rank))
+    share_gpu = os.environ.get("GCT_DP_SHARE_GPU", "0") != "0"      # TEST RIG (one-GPU boxes): every rank on cuda:0,
+    if share_gpu:                                                   # gradients through host memory over gloo
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world_size > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world_size, device_id=device)
+        if share_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world_size)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world_size, device_id=device)
     set_seed(args.seed)
     os.makedirs(args.model_folder, exist_ok=True)
     LOG = get_logger("train", os.path.join(args.model_folder, "records.log"))
@@ -161,7 +167,11 @@ def main(rank, world_size, argv=None):
     LOG.info(f"# total params: {total}, # train params: {trainable}")
     inner = model
     if world_size > 1:
-        model = FlatDataParallel(model)
+        kw = {}
+        if share_gpu:        # RCCL refuses two ranks on one device: the rig stages the two collectives through the host
+            from .testing import host_staged_allreduce, host_staged_broadcast
+            kw = dict(allreduce=host_staged_allreduce, broadcast=host_staged_broadcast)
+        model = FlatDataParallel(model, **kw)
     optimizer = FusedAdam(inner.parameters(), lr=args.lr, betas=(args.lr_beta1, args.lr_beta2),
                           eps=args.lr_eps, model=inner)
     if args.start_epoch > 1:
@@ -187,6 +197,8 @@ def cli(argv=None):
         return
     n = torch.cuda.device_count()
     print("device count:", n)
+    if os.environ.get("GCT_DP_RANKS"):          # test rigs: this many workers whatever the device count
+        n = int(os.environ["GCT_DP_RANKS"])
     if n > 1:                                   # reference train1.py:156-166: one proc per GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

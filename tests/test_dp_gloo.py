@@ -89,6 +89,109 @@ def test_flat_data_parallel_two_ranks(flat):
     assert all(out.get(r) for r in range(world))
 
 
+class _TrunkToy(FlatModelMixin, nn.Module):
+    """Two 'encoder layers' behind ONE autograd Function with a hand-written backward that writes the gradients through
+    engine.GradSink and reports each finished layer through engine._grads_done -- the structure of
+    engine.EncoderFn / DecoderFn, on CPU tensors."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = nn.Module()
+        self.encoder.layers = nn.ModuleList([nn.Linear(6, 6), nn.Linear(6, 6)])
+        self.out = nn.Linear(6, 3)
+
+    def forward(self, x):
+        return self.out(_TrunkFn.apply(self, x, *self.encoder.parameters()))
+
+
+_EVENTS = []
+
+
+class _TrunkFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, *params):
+        l0, l1 = mod.encoder.layers
+        a = torch.tanh(x @ l0.weight.t() + l0.bias)
+        ctx.mod, ctx.x, ctx.a, ctx.params = mod, x, a, params
+        return a @ l1.weight.t() + l1.bias
+
+    @staticmethod
+    def backward(ctx, dy):
+        from gct_plus_amd import engine
+        l0, l1 = ctx.mod.encoder.layers
+        G = engine.GradSink()
+        G(l1.weight).copy_(dy.t() @ ctx.a)
+        G(l1.bias).copy_(dy.sum(0))
+        engine._grads_done(l1, G)                         # the last layer finishes first
+        _EVENTS.append("layer1 done")
+        dh = (dy @ l1.weight) * (1 - ctx.a * ctx.a)
+        G(l0.weight).copy_(dh.t() @ ctx.x)
+        G(l0.bias).copy_(dh.sum(0))
+        engine._grads_done(l0, G)
+        _EVENTS.append("layer0 done")
+        return (None, dh @ l0.weight) + G.collect(ctx.params)
+
+
+def _trunk_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    FlatDataParallel.MIN_BUCKET_BYTES = 0                 # every run its own bucket: encoder.layers.0 | .1 | out
+    torch.manual_seed(5)
+    m = _TrunkToy()
+    m.flatten_parameters()
+    w = FlatDataParallel(m)
+    assert [g["top"] for g in w._buckets] == ["encoder.layers.0.", "encoder.layers.1.", "out"]
+    launches = []
+    real = w._launch
+    w._launch = lambda bi: (launches.append((w._buckets[bi]["top"], list(_EVENTS))), real(bi))[1]
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(rank))
+    for step in range(3):
+        for p in m.parameters():
+            p.grad = None
+        del launches[:], _EVENTS[:]
+        w(x).pow(2).sum().backward()
+        exp = {}
+        for r in range(world):                            # mean over ranks of each rank's own (plain autograd) gradient
+            xr = torch.randn(8, 6, generator=torch.Generator().manual_seed(r))
+            l0, l1 = m.encoder.layers
+            ps = [p.detach().clone().requires_grad_(True) for p in (l0.weight, l0.bias, l1.weight, l1.bias,
+                                                                   m.out.weight, m.out.bias)]
+            y = (torch.tanh(xr @ ps[0].t() + ps[1]) @ ps[2].t() + ps[3]) @ ps[4].t() + ps[5]
+            y.pow(2).sum().backward()
+            for n, p in zip(["encoder.layers.0.weight", "encoder.layers.0.bias", "encoder.layers.1.weight",
+                             "encoder.layers.1.bias", "out.weight", "out.bias"], ps):
+                exp[n] = exp.get(n, 0) + p.grad / world
+        for n, p in m.named_parameters():
+            assert torch.allclose(p.grad, exp[n], atol=1e-6), (n, step)
+        assert m.grads_are_flat()
+        order = [t for t, _ in launches]
+        if step == 0:                                     # first backward: the dead set is learned, nothing is early
+            assert all(ev == ["layer1 done", "layer0 done"] for _, ev in launches), launches
+        else:
+            # the head's bucket goes first (its AccumulateGrad fires before the trunk runs), layer 1's bucket is
+            # launched from INSIDE the trunk backward -- before layer 0 has been computed -- and layer 0's last
+            assert order == ["out", "encoder.layers.1.", "encoder.layers.0."], order
+            ev = dict(launches)
+            assert ev["out"] == [] and ev["encoder.layers.1."] == [] and ev["encoder.layers.0."] == ["layer1 done"], launches
+    # a gradient that cannot go to its flat slot (.grad kept from the last step): the bucket falls back to the end
+    del launches[:], _EVENTS[:]
+    w(x).pow(2).sum().backward()                          # no `p.grad = None`: accumulation semantics
+    assert all(ev == ["layer1 done", "layer0 done"] for t, ev in launches if t.startswith("encoder")), launches
+    out[rank] = True
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_layer_buckets_launch_from_inside_the_trunk_backward():
+    """dp.FlatDataParallel + engine.GRAD_NOTIFY: per-layer buckets of the flat gradient buffer are exchanged while the
+    layers underneath are still in their backward pass (two gloo ranks, a toy trunk with a hand-written backward)."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_trunk_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world))
+
+
 def _merge_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
