@@ -31,8 +31,6 @@ SIGNATURES = {
                                 I32, P, P, F32, U64, U32, P, I64, P]),
     "gct_linear_fwd_p": (I32, [P, I64, I64, I32, P, P, P, I64, P, I64, P, P, P, I32, I32, P, P, P, I64,
                                I32, P, P, F32, U64, U32, P, I64, P]),
-    "gct_linear_fwd_pp": (I32, [P, P, I64, I64, I64, I32, P, P, P, I64, P, I64, P, P, P, I32, I32, P, P, P, I64,
-                                I32, P, P, F32, U64, U32, P, I64, P]),
     "gct_linear_dgrad_p": (I32, [P, P, P, I64, I64, I32, I32, P, P, P, I64, P, I64, I32, P, I64, I32, P,
                                  F32, U64, U32, P, I64, P, I64, P]),
     "gct_linear_dgrad_ws_bytes": (I64, [I64, I32, I32]),

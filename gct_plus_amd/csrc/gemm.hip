@@ -73,8 +73,6 @@ struct GemmArgs {
   const int32_t* kt_count;  // device scalar: entries of kt_list
   const uint16_t* bp0;  // bf16x6 kernels: pre-split planes of the B operand (same element offsets as b)
   int64_t bp_stride;    // elements between the hi / mid / lo planes
-  const uint16_t* ap0;  // pre-split planes of the A operand (same element offsets as a.p0; nullptr: split on the fly)
-  int64_t ap_stride;
 #ifdef GCT_STAMPS
   unsigned long long* stamps;  // diagnostic build only (tools/gemm_stamps.hip)
 #endif
@@ -456,10 +454,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
 // K = 512 shapes, +1 % on the step; -DGCT_EPI_PLAIN restores ordinary stores)
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void epi_store4(float* p, const float (&x)[4]) {
-#ifdef GCT_STAMPS_NOSTORE
-  if (x[0] == 1.2345e30f) *p = x[1];     // timing-only build: keeps the values live, stores (practically) nothing
-  return;
-#endif
 #ifdef GCT_EPI_PLAIN
   *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
 #else
@@ -502,13 +496,6 @@ struct FastEpi {
   __device__ __forceinline__ void apply(float4 (&v)[4], const float4 (&ex)[4], int64_t row0,
                                         int64_t col0, float* cbase, int64_t cloc, float4 bias) const {
     // v[rr] = 4 consecutive columns (col0..col0+3) of row row0+rr; row0 % 4 == 0
-    float4 prev[4];
-    compute(v, prev, ex, row0, col0, bias);
-    store(v, prev, row0, cbase, cloc);
-  }
-  // the arithmetic of a 4 x 4 patch, in registers: v becomes the output values, prev the pre-activation (GELU epilogue)
-  __device__ __forceinline__ void compute(float4 (&v)[4], float4 (&prev)[4], const float4 (&ex)[4], int64_t row0,
-                                          int64_t col0, float4 bias) const {
     const int epi = g.epi;
     uint4 bits[2];   // one Philox call per 4 rows x 2 columns (col0 % 4 == 0)
     const bool rng = g.thr != 0u && (epi == GCT_EPI_GELU_DROP || epi == GCT_EPI_DROP_RESID ||
@@ -520,6 +507,9 @@ struct FastEpi {
     }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
+      const int64_t row = row0 + rr;
+      if (row >= g.M) break;
+      const int64_t off = row * g.ldc + cloc;
       float x[4] = {v[rr].x, v[rr].y, v[rr].z, v[rr].w};
       const float bs[4] = {bias.x, bias.y, bias.z, bias.w};
       bool keep[4] = {true, true, true, true};
@@ -533,7 +523,7 @@ struct FastEpi {
       } else if (epi == GCT_EPI_GELU_DROP) {
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) x[cc] += bs[cc];
-        prev[rr] = make_float4(x[0], x[1], x[2], x[3]);
+        epi_store4(g.pre + off, x);
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) x[cc] = keep[cc] ? gct_gelu(x[cc]) * g.keep_scale : 0.f;
       } else if (epi == GCT_EPI_DROP_RESID) {
@@ -552,22 +542,7 @@ struct FastEpi {
         for (int cc = 0; cc < 4; ++cc)
           x[cc] = keep[cc] ? x[cc] * gct_gelu_grad(us[cc]) * g.keep_scale : 0.f;
       }
-      v[rr] = make_float4(x[0], x[1], x[2], x[3]);
-    }
-  }
-  __device__ __forceinline__ void store(const float4 (&v)[4], const float4 (&prev)[4], int64_t row0, float* cbase,
-                                        int64_t cloc) const {
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int64_t row = row0 + rr;
-      if (row >= g.M) break;
-      const int64_t off = row * g.ldc + cloc;
-      if (g.epi == GCT_EPI_GELU_DROP) {
-        const float p4[4] = {prev[rr].x, prev[rr].y, prev[rr].z, prev[rr].w};
-        epi_store4(g.pre + off, p4);
-      }
-      const float x4[4] = {v[rr].x, v[rr].y, v[rr].z, v[rr].w};
-      epi_store4(cbase + off, x4);
+      epi_store4(cbase + off, x);
     }
   }
 };
@@ -634,51 +609,6 @@ __device__ __forceinline__ void wave_epilogue_tail(const GemmArgs& g, float* stg
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
         v[rr] = *reinterpret_cast<const float4*>(stg + (rg * 4 + rr) * 64 + c4 * 4);
-      ep.apply(v, ex[it], row0, col0, cbase, cloc, bias);
-    }
-  }
-}
-
-// The same tail on HALF a wave block: `stg` holds rows [32 h, 32 h + 32) of the wave's 64 x 64 block (row-major, 64
-// floats per row, the wave's own LDS writes); mw / nw are the block's first row / column as for the full tail.  Used by
-// the persistent plane-plane kernel, whose epilogue may only borrow one LDS stage (8 KB per wave).
-__device__ __forceinline__ void wave_epilogue_half(const GemmArgs& g, const float* stg, int lane, int64_t mw,
-                                                   int64_t nw, unsigned z, int h) {
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes are visible to it
-  __builtin_amdgcn_wave_barrier();
-  const FastEpi ep{g};
-  const int c4 = lane & 15;
-  const int64_t col0 = nw + c4 * 4;
-  if (col0 < g.N) {
-    float* cbase;
-    int64_t cloc;
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.epi == EPI_SLAB) {
-      cbase = g.c0 + (int64_t)z * g.slab_stride;
-      cloc = col0;
-    } else {
-      const bool g1 = col0 >= g.c_nper, g2 = col0 >= 2 * g.c_nper;
-      cloc = col0 - (g2 ? 2 * g.c_nper : (g1 ? g.c_nper : 0));
-      cbase = g.c0 + (g2 ? g.c_d2 : (g1 ? g.c_d1 : 0));
-      if (g.epi < EPI_D0 && g.bias0)
-        bias = *reinterpret_cast<const float4*>(g.bias0 + (g2 ? g.bias_d2 : (g1 ? g.bias_d1 : 0)) + cloc);
-    }
-    float4 ex[2][4];
-    const bool extra = ep.needs_extra();
-    if (extra) {
-#pragma unroll
-      for (int it = 0; it < 2; ++it)
-        ep.prefetch(ex[it], mw + ((2 * h + it) * 4 + (lane >> 4)) * 4, cbase, cloc);
-    }
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int rl = it * 4 + (lane >> 4);                  // 4-row group inside the half block
-      const int64_t row0 = mw + (8 * h + rl) * 4;
-      if (row0 >= g.M) continue;
-      float4 v[4];
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
-        v[rr] = *reinterpret_cast<const float4*>(stg + (rl * 4 + rr) * 64 + c4 * 4);
       ep.apply(v, ex[it], row0, col0, cbase, cloc, bias);
     }
   }
@@ -917,7 +847,6 @@ gemm_f32_fast_kernel(const GemmArgs g) {
 
 int64_t g_x6_kernel_launches = 0;   // gemm_x6_kernel launches (a tail-balanced call makes two)
 #include "gemm_x6.inc"
-#include "gemm_x6p.inc"
 
 // =====================================================================================
 // SKINNY-M forward kernel (KV-cached decode: M = batch rows per step = 512): 64x64 tiles, 4 waves
@@ -1278,7 +1207,6 @@ int launch_x6_tail_split(const GemmArgs& g, hipStream_t st, float* ws, int64_t w
   GemmArgs e = g;                                      // the tail rows as their own problem
   e.M = m2; e.row_base = g.row_base + m1;
   e.a.p0 += m1 * g.lda;                                // FWD / DGRAD: A is [M][K]
-  if (e.ap0) e.ap0 += m1 * g.lda;
   e.c0 += m1 * g.ldc;
   if (e.resid) e.resid += m1 * g.ldc;
   if (e.pre) e.pre += m1 * g.ldc;
@@ -1501,8 +1429,7 @@ static int linear_fwd_impl(const float* x, int64_t ldx, int64_t M, int K, const 
                            const float* b1, const float* b2, int nseg, int nper, float* y0,
                            float* y1, float* y2, int64_t ldy, int epi, const float* resid,
                            float* pre, float p, uint64_t seed, uint32_t site, float* ws, int64_t ws_bytes,
-                           void* stream, const uint16_t* wp0 = nullptr, int64_t pstride = 0,
-                           const uint16_t* xp0 = nullptr, int64_t xpstride = 0) {
+                           void* stream, const uint16_t* wp0 = nullptr, int64_t pstride = 0) {
   GCT_CHECK_ARG(x && w0 && y0 && M >= 0 && K > 0 && nseg >= 1 && nseg <= 3 && nper > 0,
                 "linear_fwd: bad args");
   GCT_CHECK_ARG(ws_bytes >= 0, "linear_fwd: negative workspace size");
@@ -1524,7 +1451,6 @@ static int linear_fwd_impl(const float* x, int64_t ldx, int64_t M, int K, const 
   g.resid = resid; g.pre = pre;
   g.thr = gct_drop_threshold(p); g.keep_scale = 1.0f / (1.0f - p); g.rng = gct_rng_make(seed, site);
   g.bp0 = wp0; g.bp_stride = pstride;
-  g.ap0 = xp0; g.ap_stride = xpstride;
   const bool vec = al16(x) && al16(w0) && al16(w1) && al16(w2) && (ldx % 4 == 0) &&
                    (ldw % 4 == 0) && (K % 4 == 0);
   return launch<true, true>(g, vec, (hipStream_t)stream, ws, ws ? ws_bytes : 0);   // every slab route checks its need against ws_bytes
@@ -1557,16 +1483,6 @@ extern "C" int gct_linear_fwd_p(const float* x, int64_t ldx, int64_t M, int K, c
                                 uint64_t seed, uint32_t site, float* ws, int64_t ws_bytes, void* stream) {
   return linear_fwd_impl(x, ldx, M, K, w0, w1, w2, ldw, b0, b1, b2, nseg, nper, y0, y1, y2, ldy, epi,
                          resid, pre, p, seed, site, ws, ws_bytes, stream, wp0, plane_stride);
-}
-
-extern "C" int gct_linear_fwd_pp(const float* x, const uint16_t* xp0, int64_t x_plane_stride, int64_t ldx, int64_t M,
-                                 int K, const float* w0, const float* w1, const float* w2, int64_t ldw,
-                                 const uint16_t* wp0, int64_t plane_stride, const float* b0, const float* b1,
-                                 const float* b2, int nseg, int nper, float* y0, float* y1, float* y2,
-                                 int64_t ldy, int epi, const float* resid, float* pre, float p,
-                                 uint64_t seed, uint32_t site, float* ws, int64_t ws_bytes, void* stream) {
-  return linear_fwd_impl(x, ldx, M, K, w0, w1, w2, ldw, b0, b1, b2, nseg, nper, y0, y1, y2, ldy, epi,
-                         resid, pre, p, seed, site, ws, ws_bytes, stream, wp0, plane_stride, xp0, x_plane_stride);
 }
 
 extern "C" int gct_gemm_set_mode(int mode) {

@@ -58,6 +58,7 @@ class KVDecoder:
         self.graphs = {}
         self.graph_replay = True
         self.replay_probe = None                          # numbers of the replay guard (after the first capture)
+        self._fold_key = None                             # what the cached folded projections were computed from
         self._shape = None
 
     # -------------------------------------------------------------------------------------
@@ -111,6 +112,7 @@ class KVDecoder:
                 # folded projections of all layers in ONE flat buffer (its bf16 planes serve the bf16x6 GEMMs)
                 per = 2 * self.nq * d
                 self.zflat = torch.empty(len(dec.layers) * per, device=dev)
+                self._fold_key = None                      # new buffers: nothing folded in them yet
                 self.zq_w = [self.zflat[i * per:i * per + self.nq * d].view(self.nq, d) for i in range(len(dec.layers))]
                 self.zo_w = [self.zflat[i * per + self.nq * d:(i + 1) * per].view(d, self.nq) for i in range(len(dec.layers))]
                 self.zq_b = [torch.empty(self.nq, device=dev) for _ in dec.layers]
@@ -161,13 +163,31 @@ class KVDecoder:
                            [kv, kv[:, d:]], 2 * d)
 
     def _fold_cross(self, cl):
-        """Once per sequence, weights only (+ the n_c condition rows): the cross-attention of layer l over the memory
+        """Once per sequence (the n_c condition rows) on top of a weights-only part that is CACHED across start()
+        calls while the weights stay the same (`model.weights_token()`): the cross-attention of layer l over the memory
         e = fc_z(z) is rewritten over z itself (gct_attn_decode_z).  With G = W_k W_z, Hm = W_v W_z (d x latent) and
         the block-diagonal BD[h*lat + c, h*dk + r] = G[h*dk + r, c]:
             folded query    q' = BD (W_q x + b_q)            -> zq_w = [W_q ; BD W_q], zq_b = [b_q ; BD b_q]
             folded output   y  = W_o (o_cond + BDH ctx) + b_o + W_o d   with d = W_v b_z + b_v
         (the key-side constant c = W_k b_z + b_k shifts every score of a row equally and drops out of the softmax; the
         condition rows keep explicit keys / values, shifted by -c / -d so that they share the softmax and the bias)."""
+        dec, d = self.dec, self.d
+        token = self.model.weights_token() if hasattr(self.model, "weights_token") else None
+        key = (token, ops.gemm_get_mode(), self.nq, self.nz, self.zflat.data_ptr())
+        if token is None or self._fold_key != key:
+            self._fold_weights()
+            self._fold_key = key
+        off = self.nq - self.nz
+        if off:                                                     # condition rows: k - c | v - d
+            for li, layer in enumerate(dec.layers):
+                a, kv = layer.attn_2, self.ckv[li]
+                ops.linear_fwd(cl, [a.k_linear.weight, a.v_linear.weight], [a.k_linear.bias, a.v_linear.bias],
+                               [kv, kv[:, d:]], 2 * d)
+                kv.view(-1, 2, d).sub_(self.zcv[li].view(1, 2, d))
+
+    def _fold_weights(self):
+        """The weights-only part of _fold_cross (43 ms of small GEMMs and index fills for six layers: 15 % of a whole
+        n = 4096 decode before it was cached)."""
         dec, d, H, dk, dev = self.dec, self.d, self.H, self.dk, self.zflat.device
         lat = self.nz // H
         Wz, bz = dec.fc_z.weight, dec.fc_z.bias
@@ -180,6 +200,7 @@ class KVDecoder:
             bd[hh, :, hh, :] = M.view(H, dk, lat).transpose(1, 2)
             return bd.view(H * lat, d)
 
+        self.zcv = []
         for li, layer in enumerate(dec.layers):
             a = layer.attn_2
             G, Hm = torch.empty(d, lat, device=dev), torch.empty(d, lat, device=dev)
@@ -188,6 +209,7 @@ class KVDecoder:
             cv = torch.empty(2, d, device=dev)                                      # c = W_k b_z + b_k ; d = W_v b_z + b_v
             ops.linear_fwd(bz.view(1, d), [a.k_linear.weight], [a.k_linear.bias], [cv[0:1]], d)
             ops.linear_fwd(bz.view(1, d), [a.v_linear.weight], [a.v_linear.bias], [cv[1:2]], d)
+            self.zcv.append(cv)
             BD, BDH = blockdiag(G), blockdiag(Hm)
             qw, ow = self.zq_w[li], self.zo_w[li]
             ops.linear_fwd(BD, [a.q_linear.weight.t().contiguous()], [None], [qw[off:]], d)          # BD W_q
@@ -198,10 +220,6 @@ class KVDecoder:
                 qw[:off].copy_(a.q_linear.weight)
                 self.zq_b[li][:off].copy_(a.q_linear.bias)
                 ow[:, :off].copy_(a.out.weight)
-                kv = self.ckv[li]                                   # condition rows: k - c | v - d
-                ops.linear_fwd(cl, [a.k_linear.weight, a.v_linear.weight], [a.k_linear.bias, a.v_linear.bias],
-                               [kv, kv[:, d:]], 2 * d)
-                kv.view(-1, 2, d).sub_(cv.view(1, 2, d))
         if ops.gemm_get_mode() == ops.GEMM_BF16X6:
             self.zplanes = ops.split_planes(self.zflat, self.zplanes)
             ops.register_planes(self.zflat, self.zplanes)

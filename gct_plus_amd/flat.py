@@ -100,9 +100,21 @@ class FlatModelMixin:
         ops.split_planes(f["params"], f["planes"])
         ops.register_planes(f["params"], f["planes"])
 
+    def weights_token(self):
+        """Changes whenever the weights may have changed: (raw-write epoch, version counter of the flat parameter
+        buffer, its address).  Every torch in-place operation on a parameter bumps the version counter its view shares
+        with the flat buffer (load_state_dict, copy_, DDP-style broadcasts); the one writer that goes behind torch's
+        back -- FusedAdam's kernel -- reports through invalidate_weight_planes(), which bumps the epoch.  Caches of
+        anything derived from the weights alone (decode.KVDecoder's folded cross-attention projections) key on it."""
+        f = self._gct_flat
+        if f is None:
+            return None
+        return (getattr(self, "_gct_epoch", 0), f["params"]._version, f["params"].data_ptr())
+
     def invalidate_weight_planes(self):
         """Called by whoever rewrites the weights behind autograd's back (FusedAdam): GEMMs fall back
         to the fp32 kernels until the next refresh instead of reading stale planes."""
+        self._gct_epoch = getattr(self, "_gct_epoch", 0) + 1
         f = self._gct_flat
         if f is not None and "planes" in f:
             from . import ops

@@ -279,12 +279,10 @@ def _plane_ptr(ws_):
 
 def linear_fwd(x2d, ws_: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Tensor]],
                outs: Sequence[torch.Tensor], ldy: int, epi=EPI_BIAS, resid=None, pre=None,
-               p=0.0, seed=0, site=0, splitk_ws: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
-               xplanes: Optional[torch.Tensor] = None):
+               p=0.0, seed=0, site=0, splitk_ws: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None):
     """y_s = epi(x @ w_s^T + b_s); outs are (views of) pre-allocated [M, nper] blocks with
     leading dimension ldy.  splitk_ws: force the skinny-M split-K kernel with this workspace; ws: a caller-owned
-    workspace (>= gct_linear_fwd_ws_bytes) for the general path (fixed address: graph capture); xplanes: int16
-    [3, ...] bf16 pieces of x2d in x2d's own layout (split_planes / a plane-emitting producer)."""
+    workspace (>= gct_linear_fwd_ws_bytes) for the general path (fixed address: graph capture)."""
     M, K = x2d.shape
     nper = ws_[0].shape[0]
     w = _seg3(ws_)
@@ -303,13 +301,6 @@ def linear_fwd(x2d, ws_: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Ten
         return
     wp, pstride = _plane_ptr(ws_)
     wsb = ws if ws is not None else (workspace(need, x2d.device) if need > 256 else None)
-    if xplanes is not None and wp is not None:
-        with _Timed("gemm_fwd", 2.0 * M * K * nper * len(ws_)):
-            check(_L().gct_linear_fwd_pp(_p(x2d), _p(xplanes), xplanes.stride(0), x2d.stride(0), M, K, w[0], w[1], w[2],
-                                         ws_[0].stride(0), wp, pstride, b[0], b[1], b[2], len(ws_), nper, y[0], y[1],
-                                         y[2], ldy, epi, _p(resid), _p(pre), p, seed, site, _p(wsb),
-                                         0 if wsb is None else wsb.numel() * 4, _st()), "gct_linear_fwd_pp")
-        return
     with _Timed("gemm_fwd", 2.0 * M * K * nper * len(ws_)):
         check(_L().gct_linear_fwd_p(_p(x2d), x2d.stride(0), M, K, w[0], w[1], w[2], ws_[0].stride(0),
                                     wp, pstride, b[0], b[1], b[2], len(ws_), nper, y[0], y[1], y[2],

@@ -165,17 +165,6 @@ int gct_linear_fwd_p(const float* x, int64_t ldx, int64_t M, int K,
                      int nseg, int nper, float* y0, float* y1, float* y2, int64_t ldy,
                      int epi, const float* resid, float* pre, float p, uint64_t seed, uint32_t site,
                      float* ws, int64_t ws_bytes, void* stream);
-/* gct_linear_fwd_p with the activation's bf16 planes as well (xp0: plane 0 of x, same [M][ldx] layout, planes
- * x_plane_stride elements apart -- what gct_split_planes or a plane-emitting producer wrote): launches that qualify move
- * both operands into LDS by LDS-DMA with no split arithmetic in the kernel; the sums are bit-identical to
- * gct_linear_fwd_p's (the same six partial products of the same pieces).  xp0 == NULL: gct_linear_fwd_p. */
-int gct_linear_fwd_pp(const float* x, const uint16_t* xp0, int64_t x_plane_stride, int64_t ldx, int64_t M, int K,
-                      const float* w0, const float* w1, const float* w2, int64_t ldw,
-                      const uint16_t* wp0, int64_t plane_stride,
-                      const float* b0, const float* b1, const float* b2,
-                      int nseg, int nper, float* y0, float* y1, float* y2, int64_t ldy,
-                      int epi, const float* resid, float* pre, float p, uint64_t seed, uint32_t site,
-                      float* ws, int64_t ws_bytes, void* stream);
 int gct_linear_dgrad_p(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
                        int64_t M, int nseg, int nper,
                        const float* w0, const float* w1, const float* w2, int64_t ldw,

@@ -100,6 +100,50 @@ def test_kv_decode_full_size_pscavaetf_vs_oracle_loop(graphs):
         assert float(top2[0] - top2[1]) < 1e-4, (b, t, top2.tolist(), ys[b].tolist(), ref[b].tolist())
 
 
+def test_folded_cross_attention_is_cached_until_the_weights_change():
+    """KVDecoder._fold_weights (the weights-only part of the latent cross-attention fold) runs once per set of weights:
+    a second start() reuses it; an in-place torch update of a parameter (version counter) or a FusedAdam step (raw
+    kernel write, reported through invalidate_weight_planes) triggers a re-fold, and the ids follow the new weights."""
+    from gct_plus_amd.decode import KVDecoder, reference_style_decode
+    from gct_plus_amd.optim import FusedAdam
+    mtype = "pvaetf"
+    model = build(mtype)
+    nc = synthetic.n_conds(mtype)
+    n, Le = 6, 9 + nc
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(n, Le, 16, generator=g).cuda()
+    dconds = torch.randn(n, nc, generator=g).cuda()
+    src_mask = torch.ones(n, 1, Le, dtype=torch.bool, device="cuda")
+    ys0 = torch.full((n, 1), synthetic.SOS_ID, dtype=torch.long, device="cuda")
+    kd = KVDecoder(model, synthetic.PAD_ID, synthetic.SOS_ID, eos_id=-1)
+    calls = []
+    real = kd._fold_weights
+    kd._fold_weights = lambda: (calls.append(1), real())[1]
+
+    def run():
+        kd.start(z, src_mask, dconds, max_total_len=32)
+        assert kd.zattn
+        ys = kd.generate(ys0, max_strlen=14)
+        ref = reference_style_decode(model, z, src_mask, dconds, ys0, synthetic.PAD_ID, -1, 14)
+        assert torch.equal(ys, ref)
+
+    run()
+    run()
+    assert len(calls) == 1                                          # same weights: folded once
+    with torch.no_grad():
+        model.decoder.layers[0].attn_2.k_linear.weight.mul_(1.5)    # torch in-place update: version counter
+    run()
+    assert len(calls) == 2
+    model.train()
+    opt = FusedAdam(model.parameters(), lr=1e-2, betas=(0.9, 0.98), eps=1e-9, model=model)
+    for p in model.parameters():
+        p.grad = torch.randn_like(p) * 0.1
+    opt.step()                                                      # raw kernel write behind torch's back
+    model.eval()
+    run()
+    assert len(calls) == 3
+
+
 def test_multinomial_matches_probabilities():
     """Sampling cannot share an RNG stream with torch.multinomial; compare at the probability
     level: empirical frequencies of the first sampled token vs softmax(logits)."""

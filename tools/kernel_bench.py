@@ -59,42 +59,6 @@ def gemm_suite(reps, only=None):
                   flush=True)
 
 
-def gemmpp_suite(reps, only=None):
-    """Forward GEMMs with the activation pre-split as well (gct_linear_fwd_pp: both operands by LDS-DMA) against the
-    kernel that splits the activation on the fly, interleaved rounds in one process; the outputs must be bit-identical."""
-    dev = "cuda"
-    shapes = [("qkv", 40960, 512, 512, 3, ops.EPI_BIAS), ("out", 40960, 512, 512, 1, ops.EPI_DROP_RESID),
-              ("ffn1", 40960, 512, 2048, 1, ops.EPI_GELU_DROP), ("ffn2", 40960, 2048, 512, 1, ops.EPI_DROP_RESID),
-              ("kv", 20480, 512, 512, 2, ops.EPI_BIAS), ("sq4k", 4096, 4096, 4096, 1, ops.EPI_BIAS)]
-    for name, M, K, nper, nseg, epi in shapes:
-        if only and name not in only:
-            continue
-        N = nper * nseg
-        x = torch.randn(M, K, device=dev)
-        xp = ops.split_planes(x.view(-1))
-        wflat = torch.randn(nseg * nper * K, device=dev) * K ** -0.5
-        ws = [wflat[s * nper * K:(s + 1) * nper * K].view(nper, K) for s in range(nseg)]
-        ops.register_planes(wflat, ops.split_planes(wflat))
-        bs = [torch.randn(nper, device=dev) for _ in range(nseg)]
-        y0, y1 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
-        resid = torch.randn(M, N, device=dev) if epi == ops.EPI_DROP_RESID else None
-        pre = torch.empty(M, N, device=dev) if epi == ops.EPI_GELU_DROP else None
-        kw = dict(epi=epi, resid=resid, pre=pre, p=0.1, seed=5, site=3)
-        f0 = lambda: ops.linear_fwd(x, ws, bs, [y0[:, s * nper:] for s in range(nseg)], N, **kw)        # noqa: E731
-        f1 = lambda: ops.linear_fwd(x, ws, bs, [y1[:, s * nper:] for s in range(nseg)], N, xplanes=xp, **kw)   # noqa: E731
-        f0(); f1()
-        torch.cuda.synchronize()
-        same = torch.equal(y0, y1)
-        fl = 2.0 * M * K * N
-        t0s, t1s = [], []
-        for _ in range(3):                                      # interleaved rounds
-            t0s.append(timeit(f0, reps)[0])
-            t1s.append(timeit(f1, reps)[0])
-        t0, t1 = sorted(t0s)[1], sorted(t1s)[1]
-        print(f"gemmpp {name:5s} M={M} K={K} N={N}: on-the-fly {t0*1e6:7.1f} us {fl/t0/1e12:6.1f} TF | planes "
-              f"{t1*1e6:7.1f} us {fl/t1/1e12:6.1f} TF | x{t0/t1:5.3f} | bit-identical {same}", flush=True)
-
-
 def decgemm_suite(reps):
     """Forward GEMMs of a KV-cached decode step (n rows) and of small training batches."""
     dev = "cuda"
@@ -178,8 +142,6 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if "gemm" in a.suite.split(","):
         gemm_suite(a.reps, a.only.split(",") if a.only else None)
-    if "gemmpp" in a.suite.split(","):
-        gemmpp_suite(a.reps, a.only.split(",") if a.only else None)
     if "decgemm" in a.suite:
         decgemm_suite(a.reps)
     if "attn" in a.suite:
