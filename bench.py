@@ -56,6 +56,8 @@ def parse_args(argv=None):
     ap.add_argument("--model-type", default="vaetf", choices=["vaetf", "pvaetf", "scavaetf", "pscavaetf"])
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--fixed-len", action="store_true", help="headline region on unpadded (all 80-token) batches")
+    ap.add_argument("--dense-decoder", action="store_true",
+                    help="compute every decoder row in the forward pass (the trainer skips the rows of padded targets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--all-kernel-timing", action="store_true")
@@ -209,7 +211,9 @@ def hip_workload(a, dev, world, rank):
     pad_id, beta = synthetic.PAD_ID, 0.04
 
     def fwd_loss(batch):
-        prop, mol, mu, lv, _ = forward_propagation[mtype](model, batch, pad_id, False)
+        # exactly what Train/trainer1.run_epoch does per step (skip_ignored: decoder rows of padded targets are not
+        # computed -- they never reach the ignore_index loss; --dense-decoder measures without the shortcut)
+        prop, mol, mu, lv, _ = forward_propagation[mtype](model, batch, pad_id, False, skip_ignored=not a.dense_decoder)
         ys = batch["trg"][:, 1:].contiguous().view(-1)
         ys_cond = batch["dconds"].unsqueeze(2).contiguous().view(-1, nc, 1) if nc else None
         loss, _, _, _ = loss_function(beta, prop, mol, ys_cond, ys, mu, lv, False, pad_id)

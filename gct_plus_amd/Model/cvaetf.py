@@ -66,10 +66,13 @@ class Decoder(nn.Module, _TrunkParams):
         self.layers = get_clones(DecoderLayer(h, d_model, dff, dropout, get_attn), N)
         self.norm = Norm(d_model)
 
-    def forward(self, trg, z, src_mask, trg_mask, dconds=None):
+    def forward(self, trg, z, src_mask, trg_mask, dconds=None, loss_rows=None):
+        """loss_rows: see Model/vaetf.py Decoder.forward (an extension of this build)."""
         run = engine.Run(self.p, self.training)
+        if loss_rows is not None:
+            loss_rows = loss_rows.to(torch.uint8).contiguous()
         outs = engine.DecoderFn.apply(self, run, trg.contiguous(), z, ops.to_mask_u8(src_mask),
-                                      ops.to_mask_u8(trg_mask), dconds, self.get_attn,
+                                      ops.to_mask_u8(trg_mask), dconds, self.get_attn, loss_rows,
                                       *self.trunk_params())
         if self.get_attn:
             n = self.N
@@ -110,9 +113,12 @@ class Cvaetf(FlatModelMixin, nn.Module):
         return self.out(x)
 
     @planes_scope
-    def forward(self, src, trg, src_mask, trg_mask, econds=None, dconds=None):
+    def forward(self, src, trg, src_mask, trg_mask, econds=None, dconds=None, *, loss_rows=None):
+        """Reference signature (Model/cvaetf.py:179) plus the keyword-only loss_rows extension of Vaetf.forward."""
         z, mu, log_var = self.encoder(src, src_mask, econds)[:3]
-        d_output = self.decoder(trg, z, src_mask, trg_mask, dconds)
+        if self.get_attn or (self.use_cond2dec and self.nconds > 0):
+            loss_rows = None
+        d_output = self.decoder(trg, z, src_mask, trg_mask, dconds, loss_rows)
         if self.get_attn:
             d_output = d_output[0]
         output = self.out(d_output)

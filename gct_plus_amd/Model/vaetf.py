@@ -76,10 +76,14 @@ class Decoder(nn.Module, _TrunkParams):
         if use_cond2lat and nconds > 0:
             self.embed_cond2lat = nn.Linear(nconds, d_model * nconds)
 
-    def forward(self, trg, z, src_mask, trg_mask, dconds):
+    def forward(self, trg, z, src_mask, trg_mask, dconds, loss_rows=None):
+        """loss_rows (bool / uint8 [B, T], optional -- an extension of this build): the rows whose output reaches the
+        loss; the others are not computed and come back as zeros (engine.decoder_trunk_fwd)."""
         run = engine.Run(self.p, self.training)
+        if loss_rows is not None:
+            loss_rows = loss_rows.to(torch.uint8).contiguous()
         outs = engine.DecoderFn.apply(self, run, trg.contiguous(), z, ops.to_mask_u8(src_mask),
-                                      ops.to_mask_u8(trg_mask), dconds, self.get_attn,
+                                      ops.to_mask_u8(trg_mask), dconds, self.get_attn, loss_rows,
                                       *self.trunk_params())
         if self.get_attn:
             n = self.N
@@ -129,10 +133,16 @@ class Vaetf(FlatModelMixin, nn.Module):
         return self.out(x)
 
     @planes_scope
-    def forward(self, src, trg, src_mask, trg_mask, econds=None, dconds=None):
+    def forward(self, src, trg, src_mask, trg_mask, econds=None, dconds=None, *, loss_rows=None):
+        """Reference signature (Model/vaetf.py:154) plus one keyword-only extension: loss_rows (bool [B, T]) names the
+        decoder rows whose logits reach the loss -- the trainer passes `ys != pad` (Model/forward_propagation1.py); the
+        other rows are then not computed at all and their logits come back as `out.bias` (the decoder output is zero
+        there), NOT as the reference's values.  Default (None): every row, as the reference."""
         x, enc_attn = self.encoder.trunk(src, src_mask, econds)
         z, mu, log_var = self.sampler(x)
-        d = self.decoder(trg, z, src_mask, trg_mask, dconds)
+        if self.get_attn or (self.use_cond2dec and self.nconds > 0):
+            loss_rows = None
+        d = self.decoder(trg, z, src_mask, trg_mask, dconds, loss_rows)
         if self.get_attn:
             d, dec_attn_1, dec_attn_2 = d
         output = self.out(d)

@@ -62,8 +62,10 @@ def run_epoch(args, model, optimizer, dataloader, current_step, beta, LOG, train
         current_step += 1
         n_onebatch = batch['src'].size(0)
         model_cost_time -= time()
+        # skip_ignored: the decoder rows of padded targets never reach this loss (ignore_index below) -- the model does
+        # not compute them (engine.decoder_trunk_fwd; GCT_COMPACT_FWD=0 switches the shortcut off)
         preds_prop, preds_mol, mu, log_var, _ = forward_propagation[args.model_type](
-            model, batch, args.pad_id, args.use_cond2dec)[:5]
+            model, batch, args.pad_id, args.use_cond2dec, skip_ignored=True)[:5]
         model_cost_time += time()
         ys_cond = batch['dconds'].unsqueeze(2).contiguous().view(-1, nprop, 1) if nprop > 0 else None
         ys_mol = batch['trg'][:, 1:].contiguous().view(-1)

@@ -30,7 +30,7 @@ SIGNATURES = {
     "gct_linear_fwd_ws": (I32, [P, I64, I64, I32, P, P, P, I64, P, P, P, I32, I32, P, P, P, I64,
                                 I32, P, P, F32, U64, U32, P, I64, P]),
     "gct_linear_fwd_p": (I32, [P, I64, I64, I32, P, P, P, I64, P, I64, P, P, P, I32, I32, P, P, P, I64,
-                               I32, P, P, F32, U64, U32, P, I64, P]),
+                               I32, P, P, F32, U64, U32, P, I64, P, P]),
     "gct_linear_dgrad_p": (I32, [P, P, P, I64, I64, I32, I32, P, P, P, I64, P, I64, I32, P, I64, I32, P,
                                  F32, U64, U32, P, I64, P, I64, P]),
     "gct_linear_dgrad_ws_bytes": (I64, [I64, I32, I32]),
@@ -43,6 +43,7 @@ SIGNATURES = {
                                F32, U64, U32, P]),
     "gct_linear_wgrad": (I32, [P, P, P, I64, I64, I32, I32, P, I64, I32, P, P, P, I64, P, P, P,
                                P, P]),
+    "gct_dead_rows_nonzero": (I32, [P, I64, I64, I32, P, P, P]),
     "gct_nonzero_row_tiles": (I32, [P, I64, I64, I32, P, P, P, P]),
     "gct_live_rows": (I32, [P, I64, I32, I32, I32, P, I64, I64, P, P, P, P, P, P, P, P, P, P]),
     "gct_gather_quads": (I32, [P, I64, I64, P, I64, I32, P, I64, P]),
@@ -51,7 +52,7 @@ SIGNATURES = {
                                   P, P, P, P]),
     "gct_dropout_bwd": (I32, [P, P, I64, I32, F32, U64, U32, P, P]),
     "gct_attn_fwd": (I32, [P, I64, P, I64, P, I64, P, I64, I64, P, I64, P, P, I32, I32, I32, I32,
-                           I32, F32, F32, U64, U32, P, P, P, I64, I64, P]),
+                           I32, F32, F32, U64, U32, P, P, P, I64, I64, P, P, P]),
     "gct_attn_bwd": (I32, [P, I64, P, I64, P, I64, P, I64, I64, P, P, I64, P, P, I64, P, I64,
                            P, I64, I32, I32, I32, I32, I32, F32, F32, U64, U32, P, P, I32, P, P, P, I64, I64, P, I64, P]),
     "gct_attn_bwd_ws_bytes": (I64, [I32, I32, I32, I32]),
@@ -81,7 +82,7 @@ SIGNATURES = {
     "gct_graph_census": (I32, [P, P]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _lib = None
 
 

@@ -64,6 +64,9 @@ struct AttnArgs {
   // nlive[b] query rows exist; kv_compact: dk / dv (self-attention) live in the same compact rows
   const int32_t *cstart, *nlive;
   int kv_compact;
+  // the FORWARD ran on the compact query rows as well (decoder forward over the live rows): in the forward q and o,
+  // in the backward q and o_in, live at rows cstart[b] .. cstart[b] + nlive[b] like dout / dq
+  int qo_compact;
   // compacted keys / values (cross-attention over the encoder memory without its padded rows): the K / V rows of
   // sample b start at kstart[b] and only its first klen[b] keys exist (the rest are masked keys: zero rows in LDS);
   // the backward's dk / dv live in the same rows
@@ -527,6 +530,11 @@ __global__ __launch_bounds__(256, GCT_FWD_OCC) void attn_fwd_direct_kernel(const
   const int pair = item / nqt, u = item - pair * nqt;
   const int b = pair / a.H, h = pair - b * a.H;
   const int q = 16 * u + c16;
+  // compact query rows (the decoder forward over its live rows): q / o rows of sample b start at cstart[b], only the
+  // first nlive[b] exist; a tile without a row has no work
+  const int Lq_e = a.qo_compact ? a.nlive[b] : a.Lq;
+  const int64_t qr0 = a.qo_compact ? (int64_t)a.cstart[b] : (int64_t)b * a.Lq;
+  if (16 * u >= Lq_e) return;
   const int Lk_in = a.klen ? a.klen[b] : a.Lk;            // keys that exist as rows; the others are masked keys
   const int64_t kr0 = a.kstart ? (int64_t)a.kstart[b] : (int64_t)b * a.Lk;
   const int klast = Lk_in > 0 ? Lk_in - 1 : 0;
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(256, GCT_FWD_OCC) void attn_fwd_direct_kernel(const
   // Q rows of this tile and the K rows of the visible key tiles arrive coalesced and become row-per-lane fragments in
   // the wave's LDS tiles (WaveTile); rows beyond the existing keys re-read the last one: their scores are masked
   VT tq[4];
-  tile_load<NDT>(tq, reinterpret_cast<const char*>(a.q + (int64_t)b * a.Lq * a.ldq + h * DK), a.ldq, 16 * u, a.Lq - 1, g, c16);
+  tile_load<NDT>(tq, reinterpret_cast<const char*>(a.q + qr0 * a.ldq + h * DK), a.ldq, 16 * u, Lq_e - 1, g, c16);
   uint4 mraw[(MW + 3) / 4] = {};
   if (a.mbits) mask_row_raw<MW>(mraw, a, b, q);
   const char* kbase = reinterpret_cast<const char*>(a.k + kr0 * a.ldk + h * DK);                  // wave-uniform
@@ -633,7 +641,7 @@ __global__ __launch_bounds__(256, GCT_FWD_OCC) void attn_fwd_direct_kernel(const
   l += __shfl_xor(l, 32, 64);
   const float inv = l > 0.f ? 1.0f / l : 0.f;
   const int64_t grow = ((int64_t)b * a.H + h) * a.Lq + q;
-  if (g == 0 && q < a.Lq) (a.lse + ((int64_t)b * a.H + h) * a.Lq)[q] = (rowvis ? m : 0.f) + __logf(l);
+  if (g == 0 && q < Lq_e) (a.lse + ((int64_t)b * a.H + h) * a.Lq)[q] = (rowvis ? m : 0.f) + __logf(l);
   uint64_t keep = keep_bits_row<NT>(a, (uint32_t)grow, use, g);
   if (a.klen) {                        // keys without a row: V is zero there (only a row that sees no key weighs them)
     uint64_t exist = 0;
@@ -676,8 +684,8 @@ __global__ __launch_bounds__(256, GCT_FWD_OCC) void attn_fwd_direct_kernel(const
     }
   }
   ASTAMP(5);                           // V arrival, P.V issued
-  if (q < a.Lq) {
-    char* obase = reinterpret_cast<char*>(a.o + (int64_t)b * a.Lq * a.ldo + h * DK);             // wave-uniform
+  if (q < Lq_e) {
+    char* obase = reinterpret_cast<char*>(a.o + qr0 * a.ldo + h * DK);                           // wave-uniform
     const uint32_t ooff = (uint32_t)((q * a.ldo + 4 * NDT * g) * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {      // accumulator row i of group g is head column NDT (4g + i) + dt
@@ -1025,17 +1033,19 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_kernel(const AttnArgs a) {
   {
     // this tile's Q, dO and O rows: coalesced -> the wave's LDS tiles -> row-per-lane fragments
     float4 bo[NDT];
-    const char* qb = reinterpret_cast<const char*>(a.q + (int64_t)b * a.Lq * a.ldq + h * DK);
+    const int64_t qrow0 = a.qo_compact ? drow0 : (int64_t)b * a.Lq;          // row of (b, 0) in q / o_in
+    const int qlast = (a.qo_compact ? Lq_e : a.Lq) - 1;
+    const char* qb = reinterpret_cast<const char*>(a.q + qrow0 * a.ldq + h * DK);
     const char* db = reinterpret_cast<const char*>(a.dout + drow0 * a.ldo + h * DK);
-    const char* ob = reinterpret_cast<const char*>(a.o_in + (int64_t)b * a.Lq * a.ldo + h * DK);
-    tile_load<NDT>(b0.kt, qb, a.ldq, 16 * u, a.Lq - 1, g, c16);
+    const char* ob = reinterpret_cast<const char*>(a.o_in + qrow0 * a.ldo + h * DK);
+    tile_load<NDT>(b0.kt, qb, a.ldq, 16 * u, qlast, g, c16);
     tile_load<NDT>(b0.vt, db, a.ldo, 16 * u, Lq_e - 1, g, c16);
     lse0 = a.lse_in[lrow0 + (q < a.Lq ? q : a.Lq - 1)];
     if (a.mbits) mask_row_raw<MW>(mraw, a, b, q);
     T0.put(b0.kt, g, c16);
     T0.get(bq, g, c16);
     T1.put(b0.vt, g, c16);
-    tile_load<NDT>(b0.kt, ob, a.ldo, 16 * u, a.Lq - 1, g, c16);
+    tile_load<NDT>(b0.kt, ob, a.ldo, 16 * u, qlast, g, c16);
     T1.get(bd, g, c16);
     T0.put(b0.kt, g, c16);
     T0.get(bo, g, c16);
@@ -1212,10 +1222,12 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dkv_kernel(const AttnArgs a) 
   const float4* meta = a.ws_meta + (int64_t)pair * LQP;
   const uint32_t* kp = a.ws_keep + (int64_t)pair * LQP * MW + kw;
   const uint32_t* mb = a.mbits ? a.mbits + (int64_t)b * a.mb_sb + kw : nullptr;
-  const char* qbase = reinterpret_cast<const char*>(a.q + (int64_t)b * a.Lq * a.ldq + h * DK);    // wave-uniform
+  const int64_t qrow0 = a.qo_compact ? drow0 : (int64_t)b * a.Lq;            // row of (b, 0) in q
+  const int qlast = (a.qo_compact ? Lq_e : a.Lq) - 1;
+  const char* qbase = reinterpret_cast<const char*>(a.q + qrow0 * a.ldq + h * DK);                // wave-uniform
   const char* dbase = reinterpret_cast<const char*>(a.dout + drow0 * a.ldo + h * DK);
   auto load = [&](DkvBuf<NDT>& B_, int u) {
-    tile_load<NDT>(B_.tq, qbase, a.ldq, 16 * u, a.Lq - 1, g, c16);
+    tile_load<NDT>(B_.tq, qbase, a.ldq, 16 * u, qlast, g, c16);
     tile_load<NDT>(B_.td, dbase, a.ldo, 16 * u, Lq_e - 1, g, c16);
   };
   auto compute = [&](const DkvBuf<NDT>& B_, int u) {
@@ -1469,7 +1481,7 @@ extern "C" int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t
                             int64_t mb_sq, float* o, int64_t ldo, float* lse, float* probs, int B,
                             int H, int Lq, int Lk, int dk, float scale, float p, uint64_t seed,
                             uint32_t site, const int32_t* kstart, const int32_t* klen, const uint32_t* tbits,
-                            int64_t tb_sb, int64_t tb_su, void* stream) {
+                            int64_t tb_sb, int64_t tb_su, const int32_t* qstart, const int32_t* qlen, void* stream) {
   int rc = check_common("attn_fwd", q, ldq, k, ldk, v, ldv, mbits, mb_sb, mb_sq, B, H, Lq, Lk, dk, p);
   if (rc) return rc;
   GCT_CHECK_ARG(o && lse && ldo % 4 == 0 && gct_aligned16(o) && (int64_t)Lq * ldo * 4 < (1ll << 31), "attn_fwd: bad output");
@@ -1484,6 +1496,10 @@ extern "C" int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t
 #endif
   GCT_CHECK_ARG((kstart == nullptr) == (klen == nullptr), "attn_fwd: kstart / klen go together");
   a.kstart = kstart; a.klen = klen;
+  GCT_CHECK_ARG((qstart == nullptr) == (qlen == nullptr), "attn_fwd: qstart / qlen go together");
+  GCT_CHECK_ARG(!qstart || (Lk <= 96 && !probs && getenv("GCT_ATTN_FWD_LDS") == nullptr),
+                "attn_fwd: compact query rows need the direct kernel (Lk <= 96) and no probs output");
+  a.cstart = qstart; a.nlive = qlen; a.qo_compact = qstart ? 1 : 0;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.npairs = B * H; a.scale = scale;
   a.thr = gct_drop_threshold(p); a.keep_scale = 1.0f / (1.0f - p); a.rng = gct_rng_make(seed, site);
   const int LKP = (Lk + 15) & ~15, SD = dk + 4;
@@ -1534,9 +1550,14 @@ extern "C" int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t
 #ifdef GCT_STAMPS
   a.stamps = g_attn_stamps;
 #endif
+  // kv_compact: bit 0 = dk / dv in the compact query rows (self-attention, k / v in the forward's layout);
+  //             bit 1 = q and o are compact like dout / dq (the forward itself ran on the compact rows)
+  const int qo_compact = (kv_compact >> 1) & 1;
+  kv_compact &= 1;
   GCT_CHECK_ARG((cstart == nullptr) == (nlive == nullptr) && (!kv_compact || (cstart && Lq == Lk)),
                 "attn_bwd: cstart / nlive go together; kv_compact needs them and Lq == Lk");
-  a.cstart = cstart; a.nlive = nlive; a.kv_compact = kv_compact;
+  GCT_CHECK_ARG(!qo_compact || cstart, "attn_bwd: compact q / o rows need cstart / nlive");
+  a.cstart = cstart; a.nlive = nlive; a.kv_compact = kv_compact; a.qo_compact = qo_compact;
   GCT_CHECK_ARG((kstart == nullptr) == (klen == nullptr) && !(kstart && kv_compact),
                 "attn_bwd: kstart / klen go together and exclude kv_compact");
   a.kstart = kstart; a.klen = klen;
@@ -1568,6 +1589,10 @@ extern "C" int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t
     }
     GCT_LAUNCH_CHECK("attn_bwd (direct)");
     return GCT_OK;
+  }
+  if (qo_compact) {
+    gct_set_error("attn_bwd: compact q / o rows need the direct kernels (Lk <= 96 and a workspace)");
+    return GCT_ERR_ARG;
   }
   const size_t lds = (size_t)(2 * LMX) * SD * 4 + (size_t)LQP * 8 + (size_t)LQP * MW * 8 + (size_t)LQP * 2;
   GCT_CHECK_ARG(lds <= 160 * 1024, "attn_bwd: needs %zu B of LDS", lds);

@@ -1429,9 +1429,11 @@ static int linear_fwd_impl(const float* x, int64_t ldx, int64_t M, int K, const 
                            const float* b1, const float* b2, int nseg, int nper, float* y0,
                            float* y1, float* y2, int64_t ldy, int epi, const float* resid,
                            float* pre, float p, uint64_t seed, uint32_t site, float* ws, int64_t ws_bytes,
-                           void* stream, const uint16_t* wp0 = nullptr, int64_t pstride = 0) {
+                           void* stream, const uint16_t* wp0 = nullptr, int64_t pstride = 0,
+                           const int32_t* quad_map = nullptr) {
   GCT_CHECK_ARG(x && w0 && y0 && M >= 0 && K > 0 && nseg >= 1 && nseg <= 3 && nper > 0,
                 "linear_fwd: bad args");
+  GCT_CHECK_ARG(!quad_map || M % 4 == 0, "linear_fwd: compacted rows come in quads");
   GCT_CHECK_ARG(ws_bytes >= 0, "linear_fwd: negative workspace size");
   GCT_CHECK_ARG(nseg < 2 || (w1 && y1), "linear_fwd: missing segment 1");
   GCT_CHECK_ARG(nseg < 3 || (w2 && y2), "linear_fwd: missing segment 2");
@@ -1451,6 +1453,7 @@ static int linear_fwd_impl(const float* x, int64_t ldx, int64_t M, int K, const 
   g.resid = resid; g.pre = pre;
   g.thr = gct_drop_threshold(p); g.keep_scale = 1.0f / (1.0f - p); g.rng = gct_rng_make(seed, site);
   g.bp0 = wp0; g.bp_stride = pstride;
+  g.quad_map = quad_map;          // rows are a quad compaction: the dropout coordinates of the epilogues follow the map
   const bool vec = al16(x) && al16(w0) && al16(w1) && al16(w2) && (ldx % 4 == 0) &&
                    (ldw % 4 == 0) && (K % 4 == 0);
   return launch<true, true>(g, vec, (hipStream_t)stream, ws, ws ? ws_bytes : 0);   // every slab route checks its need against ws_bytes
@@ -1480,9 +1483,10 @@ extern "C" int gct_linear_fwd_p(const float* x, int64_t ldx, int64_t M, int K, c
                                 int64_t plane_stride, const float* b0, const float* b1,
                                 const float* b2, int nseg, int nper, float* y0, float* y1, float* y2,
                                 int64_t ldy, int epi, const float* resid, float* pre, float p,
-                                uint64_t seed, uint32_t site, float* ws, int64_t ws_bytes, void* stream) {
+                                uint64_t seed, uint32_t site, float* ws, int64_t ws_bytes,
+                                const int32_t* quad_map, void* stream) {
   return linear_fwd_impl(x, ldx, M, K, w0, w1, w2, ldw, b0, b1, b2, nseg, nper, y0, y1, y2, ldy, epi,
-                         resid, pre, p, seed, site, ws, ws_bytes, stream, wp0, plane_stride);
+                         resid, pre, p, seed, site, ws, ws_bytes, stream, wp0, plane_stride, quad_map);
 }
 
 extern "C" int gct_gemm_set_mode(int mode) {

@@ -224,7 +224,30 @@ __global__ __launch_bounds__(1024) void live_compact_tiles_kernel(const uint8_t*
   }
 }
 
+// counter += number of rows r with live[r] == 0 that hold a non-zero element (one wave per row)
+__global__ __launch_bounds__(256) void dead_rows_nonzero_kernel(const float* __restrict__ g, int64_t ld, int64_t rows,
+                                                                int cols, const uint8_t* __restrict__ live,
+                                                                int32_t* __restrict__ counter) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows || live[row]) return;
+  const float* p = g + row * ld;
+  int nz = 0;
+  for (int c = lane; c < cols; c += 64) nz |= (p[c] != 0.f);
+  if (__any(nz) && lane == 0) atomicAdd(counter, 1);
+}
+
 }  // namespace
+
+extern "C" int gct_dead_rows_nonzero(const float* g, int64_t ld, int64_t rows, int cols, const uint8_t* live,
+                                     int32_t* counter, void* stream) {
+  GCT_CHECK_ARG(g && live && counter && rows >= 0 && cols > 0 && ld >= cols, "dead_rows_nonzero: bad args");
+  if (rows == 0) return GCT_OK;
+  hipLaunchKernelGGL(dead_rows_nonzero_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, ld,
+                     rows, cols, live, counter);
+  GCT_LAUNCH_CHECK("dead_rows_nonzero");
+  return GCT_OK;
+}
 
 extern "C" int gct_live_rows(const float* g, int64_t ld, int B, int T, int cols, const uint8_t* mask,
                              int64_t mask_sb, int64_t mask_sq, uint8_t* live, int32_t* n_b, int32_t* info,

@@ -117,11 +117,12 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const float* __restrict__
     const int64_t row = quad * 4 + e4;
     if (row >= rows) break;
     // qmap: dy / dres / dx are quad-compacted (csrc/liverows.hip); x, mean, rstd stay in the forward's row space
+    // (src_rows > 0) or are compacted the same way (src_rows == 0: the forward ran on the compact rows)
     int64_t srow = row;
     if (qmap) {
       const int q = qmap[row >> 2];
-      srow = (int64_t)q * 4 + (row & 3);
-      if (q < 0 || srow >= src_rows) {            // padding row: its gradient is zero
+      if (src_rows > 0) srow = (int64_t)q * 4 + (row & 3);
+      if (q < 0 || (src_rows > 0 && srow >= src_rows)) {            // padding row: its gradient is zero
         float* dr0 = dx + row * d;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -256,7 +257,7 @@ extern "C" int gct_norm_bwd(const float* dy, const float* x, const float* alpha,
   GCT_CHECK_ARG(dy && x && alpha && mean && rstd && dx && dalpha && dbias && ws,
                 "norm_bwd: null pointer");
   GCT_CHECK_ARG(!drop_out || (gct_aligned16(drop_out) && p >= 0.f && p < 1.f), "norm_bwd: bad dropout output");
-  GCT_CHECK_ARG(!quad_map || (rows % 4 == 0 && src_rows > 0), "norm_bwd: compacted rows come in quads");
+  GCT_CHECK_ARG(!quad_map || (rows % 4 == 0 && src_rows >= 0), "norm_bwd: compacted rows come in quads");
   GCT_CHECK_ARG(rows >= 0 && d >= 4 && d % 4 == 0 && d <= 256 * MAXC, "norm_bwd: d=%d unsupported", d);
   GCT_CHECK_ARG(gct_aligned16(dy) && gct_aligned16(x) && gct_aligned16(dx) && gct_aligned16(alpha) &&
                     gct_aligned16(ws) && (!dres || gct_aligned16(dres)),

@@ -32,6 +32,8 @@ COMPACT_BWD = os.environ.get("GCT_COMPACT_BWD", "1") != "0"
 COMPACT_MAX_FRACTION = 0.85
 # Cross-attention over the visible rows of the encoder memory only (decoder_trunk_fwd): GCT_COMPACT_KV=0 disables.
 COMPACT_KV = os.environ.get("GCT_COMPACT_KV", "1") != "0"
+# Decoder FORWARD over the rows that reach the loss only (decoder_trunk_fwd(loss_rows=...)): GCT_COMPACT_FWD=0 disables.
+COMPACT_FWD = os.environ.get("GCT_COMPACT_FWD", "1") != "0"
 
 
 # Data parallelism (dp.FlatDataParallel) sets this while a backward pass is running: called as
@@ -109,22 +111,27 @@ def _empty(rows, cols, like):
 
 
 # ------------------------------------------------------------------------------------- MHA
-def mha_fwd(run: Run, m, xq, xkv, B, Lq, Lk, mask_u8, resid, want_probs=False, keys=None):
+def mha_fwd(run: Run, m, xq, xkv, B, Lq, Lk, mask_u8, resid, want_probs=False, keys=None, live=None):
     """m: MultiHeadAttention module (q_linear, k_linear, v_linear, out).  xq [B*Lq,d],
     xkv [B*Lk,d] (the same tensor object for self-attention).  With `resid` the output
-    projection fuses  resid + dropout(.)  (the layer's dropout_k + residual add)."""
+    projection fuses  resid + dropout(.)  (the layer's dropout_k + residual add).
+    live (ops.LiveRows with .fwd): xq / resid / the result hold the compact query rows only (and xkv too for
+    self-attention: the live rows of a sample are a prefix, so they are also the only keys a live query can see)."""
     d, H = m.d_model, m.h
     dk = d // H
     self_attn = xkv is xq
+    Mq = xq.shape[0]
     if self_attn:
-        qkv = _empty(B * Lq, 3 * d, xq)
+        qkv = _empty(Mq, 3 * d, xq)
         ops.linear_fwd(xq, [m.q_linear.weight, m.k_linear.weight, m.v_linear.weight],
                        [m.q_linear.bias, m.k_linear.bias, m.v_linear.bias],
                        [qkv, qkv[:, d:], qkv[:, 2 * d:]], 3 * d)
         q, k, v, ldq, ldkv = qkv, qkv[:, d:], qkv[:, 2 * d:], 3 * d, 3 * d
         qb, kvb = qkv, None
+        if live is not None:
+            keys = live                                 # K / V rows of sample b: cstart[b] .. + n_b[b]
     else:
-        qb = _empty(B * Lq, d, xq)
+        qb = _empty(Mq, d, xq)
         ops.linear_fwd(xq, [m.q_linear.weight], [m.q_linear.bias], [qb], d)
         # keys (ops.KeyRows): xkv holds the VISIBLE rows of the encoder memory only (quad-compacted)
         kvb = _empty(B * Lk, 2 * d, xkv) if keys is None else keys.empty(2 * d)
@@ -133,15 +140,16 @@ def mha_fwd(run: Run, m, xq, xkv, B, Lq, Lk, mask_u8, resid, want_probs=False, k
         q, k, v, ldq, ldkv = qb, kvb, kvb[:, d:], d, 2 * d
     site_p = run.site()
     o, lse, probs = ops.attn_fwd(q, k, v, ldq, ldkv, ldkv, mask_u8, B, H, Lq, Lk, dk, run.p,
-                                 run.seed, site_p, want_probs=want_probs, keys=keys)
-    y = _empty(B * Lq, d, xq)
+                                 run.seed, site_p, want_probs=want_probs, keys=keys, live=live)
+    y = _empty(Mq, d, xq)
     site_o = run.site()
     if resid is not None:
         ops.linear_fwd(o, [m.out.weight], [m.out.bias], [y], d, epi=ops.EPI_DROP_RESID,
-                       resid=resid, p=run.p, seed=run.seed, site=site_o)
+                       resid=resid, p=run.p, seed=run.seed, site=site_o, live=live)
     else:
         ops.linear_fwd(o, [m.out.weight], [m.out.bias], [y], d)
-    saved = (xq, xkv, qb, kvb, o, lse, mask_u8, B, Lq, Lk, site_p, site_o, resid is not None, keys)
+    saved = (xq, xkv, qb, kvb, o, lse, mask_u8, B, Lq, Lk, site_p, site_o, resid is not None,
+             None if (self_attn and live is not None) else keys)
     return y, saved, probs
 
 
@@ -163,7 +171,8 @@ def mha_bwd(run: Run, m, saved, dy, G: GradSink, dxq_out, depi_q, dxkv_out=None,
         Mq, kt = live.Mc, None
         # rows of a live quad that belong to no sample's live prefix are never written by the attention kernel
         new = lambda cols: torch.zeros(live.Mc + live.SLACK, cols, dtype=torch.float32, device=dy.device)[:live.Mc]   # noqa: E731
-        o_in, xq_in = live.gather(o), live.gather(xq)
+        # (a forward that ran on the compact rows saved compact activations: nothing to gather)
+        o_in, xq_in = (o, xq) if live.fwd else (live.gather(o), live.gather(xq))
     else:
         o_in, xq_in = o, xq
     if gdrop is not None:
@@ -175,9 +184,11 @@ def mha_bwd(run: Run, m, saved, dy, G: GradSink, dxq_out, depi_q, dxkv_out=None,
     ops.linear_dgrad([g], d, Mq, [m.out.weight], do)
     if kvb is None:  # self-attention: fused [q|k|v]
         dqkv = new(3 * d)
+        fwdc = live is not None and live.fwd             # q | k | v and o are compact too: address K / V like dK / dV
         ops.attn_bwd(qb, qb[:, d:], qb[:, 2 * d:], 3 * d, 3 * d, 3 * d, mask_u8, o, do, lse, dqkv,
                      dqkv[:, d:], dqkv[:, 2 * d:], 3 * d, 3 * d, 3 * d, B, H, Lq, Lk, dk, run.p,
-                     run.seed, site_p, live=live, kv_compact=live is not None)
+                     run.seed, site_p, live=live, kv_compact=live is not None and not fwdc,
+                     keys=live if fwdc else None)
         segs = [dqkv, dqkv[:, d:], dqkv[:, 2 * d:]]
         ops.linear_wgrad(segs, 3 * d, xq_in,
                          [G(m.q_linear.weight), G(m.k_linear.weight), G(m.v_linear.weight)],
@@ -204,19 +215,19 @@ def mha_bwd(run: Run, m, saved, dy, G: GradSink, dxq_out, depi_q, dxkv_out=None,
 
 
 # ------------------------------------------------------------------------------------- FFN
-def ffn_fwd(run: Run, ff, x, resid):
+def ffn_fwd(run: Run, ff, x, resid, live=None):
     M, d = x.shape
     dff = ff.linear_1.weight.shape[0]
     pre = _empty(M, dff, x)
     hdn = _empty(M, dff, x)
     site_h = run.site()
     ops.linear_fwd(x, [ff.linear_1.weight], [ff.linear_1.bias], [hdn], dff, epi=ops.EPI_GELU_DROP,
-                   pre=pre, p=run.p, seed=run.seed, site=site_h)
+                   pre=pre, p=run.p, seed=run.seed, site=site_h, live=live)
     y = _empty(M, d, x)
     site_o = run.site()
     if resid is not None:
         ops.linear_fwd(hdn, [ff.linear_2.weight], [ff.linear_2.bias], [y], d,
-                       epi=ops.EPI_DROP_RESID, resid=resid, p=run.p, seed=run.seed, site=site_o)
+                       epi=ops.EPI_DROP_RESID, resid=resid, p=run.p, seed=run.seed, site=site_o, live=live)
     else:
         ops.linear_fwd(hdn, [ff.linear_2.weight], [ff.linear_2.bias], [y], d)
     return y, (x, pre, hdn, site_h, site_o, resid is not None)
@@ -229,8 +240,9 @@ def ffn_bwd(run: Run, ff, saved, dy, G: GradSink, dx_out, depi, live=None, gdrop
     kt = run.kt
     if live is not None:          # quad-compacted rows: gather what the forward saved
         M, kt = live.Mc, None
-        x, hdn = live.gather(x), live.gather(hdn)     # (pre stays in place: the GELU-backward epilogue reads it
-                                                      #  through the quad map)
+        if not live.fwd:                              # (a compact forward saved compact x / pre / hdn)
+            x, hdn = live.gather(x), live.gather(hdn)     # (pre stays in place: the GELU-backward epilogue reads it
+                                                          #  through the quad map)
     if gdrop is not None:
         g = gdrop
     else:
@@ -238,7 +250,7 @@ def ffn_bwd(run: Run, ff, saved, dy, G: GradSink, dx_out, depi, live=None, gdrop
     ops.linear_wgrad([g], d, hdn, [G(ff.linear_2.weight)], [G(ff.linear_2.bias)], kt=kt)
     dpre = _empty(M, dff, dy) if live is None else live.empty(dff)
     ops.linear_dgrad([g], d, M, [ff.linear_2.weight], dpre, depi=ops.DEPI_GELU_BWD, pre=pre,
-                     p=run.p, seed=run.seed, site=site_h, live=live, pre_full=live is not None)
+                     p=run.p, seed=run.seed, site=site_h, live=live, pre_full=live is not None and not live.fwd)
     ops.linear_wgrad([dpre], dff, x, [G(ff.linear_1.weight)], [G(ff.linear_1.bias)], kt=kt)
     ops.linear_dgrad([dpre], dff, M, [ff.linear_1.weight], dx_out, depi=depi)
 
@@ -282,13 +294,14 @@ def enc_layer_bwd(run: Run, layer, saved, g, G: GradSink, gd=None, gdbuf=None, b
     return g, (None if dr is None else gdbuf)
 
 
-def dec_layer_fwd(run: Run, layer, x, e, B, T, Lk, src_mask_u8, trg_mask_u8, want_probs=False, keys=None):
+def dec_layer_fwd(run: Run, layer, x, e, B, T, Lk, src_mask_u8, trg_mask_u8, want_probs=False, keys=None, live=None):
+    """live (ops.LiveRows with .fwd): x and everything row-wise of this layer hold the compact live rows only."""
     x2, m1, r1 = ops.norm_fwd(x, layer.norm_1.alpha, layer.norm_1.bias, layer.norm_1.eps)
-    xa, sv1, p1 = mha_fwd(run, layer.attn_1, x2, x2, B, T, T, trg_mask_u8, x, want_probs)
+    xa, sv1, p1 = mha_fwd(run, layer.attn_1, x2, x2, B, T, T, trg_mask_u8, x, want_probs, live=live)
     x2, m2, r2 = ops.norm_fwd(xa, layer.norm_2.alpha, layer.norm_2.bias, layer.norm_2.eps)
-    xb, sv2, p2 = mha_fwd(run, layer.attn_2, x2, e, B, T, Lk, src_mask_u8, xa, want_probs, keys=keys)
+    xb, sv2, p2 = mha_fwd(run, layer.attn_2, x2, e, B, T, Lk, src_mask_u8, xa, want_probs, keys=keys, live=live)
     x2, m3, r3 = ops.norm_fwd(xb, layer.norm_3.alpha, layer.norm_3.bias, layer.norm_3.eps)
-    xc, svf = ffn_fwd(run, layer.ff, x2, xb)
+    xc, svf = ffn_fwd(run, layer.ff, x2, xb, live=live)
     return xc, (x, m1, r1, sv1, xa, m2, r2, sv2, xb, m3, r3, svf), p1, p2
 
 
@@ -367,8 +380,17 @@ def encoder_trunk_bwd(enc, run: Run, saved, dy, G: GradSink):
                              G(enc.embed_cond2enc.bias))
 
 
-def decoder_trunk_fwd(dec, run: Run, trg, z, src_mask_u8, trg_mask_u8, dconds, want_probs=False):
-    """Model/vaetf.py:79-114.  z [B, L_e, latent]."""
+def decoder_trunk_fwd(dec, run: Run, trg, z, src_mask_u8, trg_mask_u8, dconds, want_probs=False, loss_rows=None):
+    """Model/vaetf.py:79-114.  z [B, L_e, latent].
+    loss_rows (uint8 [B, T], optional): the decoder rows whose output reaches the loss (the reference's cross-entropy
+    ignores the rows of padded targets, Train/trainer1.py:21-22: 56 % of the rows at MOSES-like lengths).  A row outside
+    the set influences a row inside it only as a KEY of self-attention, so when no live query can see a dead row under
+    THIS call's trg_mask (checked on the device, as for the compacted backward) the whole trunk runs on the quad-
+    compacted live rows: every GEMM, Norm and attention launch sees ~half the rows, every dropout site draws the bits of
+    the original coordinates, the backward finds its activations compact already.  The returned tensor has all B*T
+    rows; the skipped ones are ZERO -- or, for the few padded rows that share an aligned group of four rows with a live
+    one, finite values without meaning -- not the reference's values (nothing downstream of an ignore_index loss reads
+    them), and a gradient that arrives on a skipped row is reported as an error (ops.LiveRows.check_grad)."""
     B, T0 = trg.shape
     d, nc = dec.d_model, dec.nconds
     Le, lat = z.shape[1], z.shape[2]
@@ -398,14 +420,31 @@ def decoder_trunk_fwd(dec, run: Run, trg, z, src_mask_u8, trg_mask_u8, dconds, w
             ones = torch.ones(B, nc, dtype=torch.uint8, device=src_mask_u8.device)
             src_mask_u8 = torch.cat([ones, src_mask_u8.view(B, Le)], dim=1).contiguous()
     lsv, p1s, p2s = [], [], []
+    capturing = torch.cuda.is_current_stream_capturing()
+    # the live rows of the forward (loss_rows): one device pass builds the maps and checks the no-dead-key condition;
+    # its read-back is shared with the key-row map below (the kernels of both are queued before either is read)
+    live = None
+    lr = None
+    if (COMPACT_FWD and loss_rows is not None and not c2d and not want_probs and T <= 96 and Lk <= 96
+            and len(dec.layers) > 0 and not capturing and trg_mask_u8 is not None):
+        tm_u8 = trg_mask_u8.u8 if isinstance(trg_mask_u8, ops.MaskBits) else trg_mask_u8
+        lr = ops.LiveRows.from_rows(loss_rows.reshape(B, T), B, T, tm_u8)
     # Padded rows of the encoder memory are masked keys of every cross-attention: their K / V projections are never
     # used and their dK / dV are zero.  When src_mask is a key-padding mask whose visible keys form a prefix of
     # every sample (device check, one 32-byte read-back), the six K|V GEMMs, their weight gradients and the
     # gradient w.r.t. the memory run on the visible rows only (quad-compacted, ops.KeyRows).
     keys = None
+    kr = None
     if (COMPACT_KV and src_mask_u8 is not None and src_mask_u8.numel() == B * Lk and len(dec.layers) > 0
-            and not torch.cuda.is_current_stream_capturing()):
+            and not capturing):
         kr = ops.KeyRows(src_mask_u8.view(B, Lk), B, Lk)
+    if lr is not None:
+        h = lr.host()
+        if h["violations"] == 0 and h["nonprefix"] == 0 and 0 < h["padded"] <= COMPACT_MAX_FRACTION * B * T:
+            live = lr
+            live.fwd = True
+            x = live.gather(x)
+    if kr is not None:
         h = kr.host()
         if h["nonprefix"] == 0 and h["empty"] == 0 and 0 < h["padded"] <= COMPACT_MAX_FRACTION * B * Lk:
             keys = kr
@@ -413,18 +452,20 @@ def decoder_trunk_fwd(dec, run: Run, trg, z, src_mask_u8, trg_mask_u8, dconds, w
     src_m = ops.pack_mask(src_mask_u8, B, T, Lk)
     trg_m = ops.pack_mask(trg_mask_u8, B, T, T)
     for layer in dec.layers:
-        x, sv, p1, p2 = dec_layer_fwd(run, layer, x, e, B, T, Lk, src_m, trg_m, want_probs, keys=keys)
+        x, sv, p1, p2 = dec_layer_fwd(run, layer, x, e, B, T, Lk, src_m, trg_m, want_probs, keys=keys, live=live)
         lsv.append(sv)
         p1s.append(p1)
         p2s.append(p2)
     y, mean, rstd = ops.norm_fwd(x, dec.norm.alpha, dec.norm.bias, dec.norm.eps)
+    if live is not None:
+        y = live.scatter(y)                               # [B*T, d]: zero rows where the loss does not look
     saved = (trg, z2, dconds, site_pe, lsv, x, mean, rstd, B, T, Le, Lk, c2d, c2l,
-             trg_mask_u8.u8 if isinstance(trg_mask_u8, ops.MaskBits) else trg_mask_u8, keys)
+             trg_mask_u8.u8 if isinstance(trg_mask_u8, ops.MaskBits) else trg_mask_u8, keys, live)
     return y.view(B, T, d), saved, p1s, p2s
 
 
 def decoder_trunk_bwd(dec, run: Run, saved, dy, G: GradSink, need_dz=True):
-    trg, z2, dconds, site_pe, lsv, x_last, mean, rstd, B, T, Le, Lk, c2d, c2l, trg_mask_u8, keys = saved
+    trg, z2, dconds, site_pe, lsv, x_last, mean, rstd, B, T, Le, Lk, c2d, c2l, trg_mask_u8, keys, live_fwd = saved
     new_de = (lambda: _empty(B * Lk, d, dy)) if keys is None else (lambda: keys.empty(d))     # d(memory), maybe compact
     d, nc = dec.d_model, dec.nconds
     # A decoder row whose incoming gradient is zero (padded target positions under the ignore_index loss: 56 % of
@@ -437,8 +478,16 @@ def decoder_trunk_bwd(dec, run: Run, saved, dy, G: GradSink, need_dz=True):
     # weight-gradient GEMMs reducing over the live token tiles (the list names every tile when the check fails).
     g = dy.reshape(B * T, d)
     live = None
-    lr = ops.LiveRows(g, B, T, trg_mask_u8) if (COMPACT_BWD or (B * T) % 32 == 0) else None
-    if COMPACT_BWD and lr is not None and len(dec.layers) > 0 and not torch.cuda.is_current_stream_capturing():
+    if live_fwd is not None:
+        # the forward ran on these rows only: the backward runs on the same compact rows (what the forward saved is
+        # compact), and a gradient on a row it skipped cannot be honoured -- counted on the device, raised at the
+        # next read-back (no synchronisation here)
+        live = live_fwd
+        live.check_grad(g)
+        lr = None
+    else:
+        lr = ops.LiveRows(g, B, T, trg_mask_u8) if (COMPACT_BWD or (B * T) % 32 == 0) else None
+    if live is None and COMPACT_BWD and lr is not None and len(dec.layers) > 0 and not torch.cuda.is_current_stream_capturing():
         h = lr.host()                                   # one 32-byte read-back per step
         if h["violations"] == 0 and h["nonprefix"] == 0 and 0 < h["padded"] <= COMPACT_MAX_FRACTION * B * T:
             live = lr
@@ -522,9 +571,9 @@ class EncoderFn(torch.autograd.Function):
 
 class DecoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, dec, run, trg, z, src_mask_u8, trg_mask_u8, dconds, want_probs, *params):
+    def forward(ctx, dec, run, trg, z, src_mask_u8, trg_mask_u8, dconds, want_probs, loss_rows, *params):
         y, saved, p1, p2 = decoder_trunk_fwd(dec, run, trg, _f32c(z), src_mask_u8, trg_mask_u8,
-                                             dconds, want_probs)
+                                             dconds, want_probs, loss_rows=loss_rows)
         ctx.dec, ctx.run, ctx.saved, ctx.params = dec, run, saved, params
         ctx.need_dz = z.requires_grad
         if want_probs:
@@ -538,7 +587,7 @@ class DecoderFn(torch.autograd.Function):
         G = GradSink()
         dz = decoder_trunk_bwd(ctx.dec, ctx.run, ctx.saved, _f32c(dy), G, ctx.need_dz)
         ctx.saved = None
-        return (None, None, None, dz, None, None, None, None) + G.collect(ctx.params)
+        return (None, None, None, dz, None, None, None, None, None) + G.collect(ctx.params)
 
 
 class SamplerFn(torch.autograd.Function):

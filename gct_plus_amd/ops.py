@@ -131,10 +131,13 @@ def norm_fwd(x2d, alpha, bias, eps=1e-6, out=None):
 
 def norm_bwd(dy, x2d, alpha, mean, rstd, dalpha, dbias, dres=None, out=None, eps=1e-6, live=None, drop=None):
     """live (LiveRows): dy / dres / out are quad-compacted rows [live.Mc, d]; x2d, mean, rstd stay in the forward's
-    row space.  drop = (buffer, p, seed, site): also write dropout_bwd(result) with that mask into buffer (the
+    row space -- or, when the forward itself ran on the compact rows (live.fwd), are compact too.
+    drop = (buffer, p, seed, site): also write dropout_bwd(result) with that mask into buffer (the
     gradient's next consumer is the sub-layer whose output dropout used (seed, site))."""
     src_rows, d = x2d.shape
     rows = src_rows if live is None else live.Mc
+    if live is not None and live.fwd:
+        src_rows = 0                                   # x / mean / rstd are compact: the map only places the dropout bits
     dx = (torch.empty_like(x2d) if live is None else live.empty(d)) if out is None else out
     _wait_pending(out)
     if drop is not None:
@@ -279,10 +282,12 @@ def _plane_ptr(ws_):
 
 def linear_fwd(x2d, ws_: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Tensor]],
                outs: Sequence[torch.Tensor], ldy: int, epi=EPI_BIAS, resid=None, pre=None,
-               p=0.0, seed=0, site=0, splitk_ws: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None):
+               p=0.0, seed=0, site=0, splitk_ws: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None,
+               live=None):
     """y_s = epi(x @ w_s^T + b_s); outs are (views of) pre-allocated [M, nper] blocks with
     leading dimension ldy.  splitk_ws: force the skinny-M split-K kernel with this workspace; ws: a caller-owned
-    workspace (>= gct_linear_fwd_ws_bytes) for the general path (fixed address: graph capture)."""
+    workspace (>= gct_linear_fwd_ws_bytes) for the general path (fixed address: graph capture); live (LiveRows): the
+    rows are quad-compacted -- the dropout masks of the fused epilogues are drawn at the original coordinates."""
     M, K = x2d.shape
     nper = ws_[0].shape[0]
     w = _seg3(ws_)
@@ -305,7 +310,8 @@ def linear_fwd(x2d, ws_: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Ten
         check(_L().gct_linear_fwd_p(_p(x2d), x2d.stride(0), M, K, w[0], w[1], w[2], ws_[0].stride(0),
                                     wp, pstride, b[0], b[1], b[2], len(ws_), nper, y[0], y[1], y[2],
                                     ldy, epi, _p(resid), _p(pre), p, seed, site, _p(wsb),
-                                    0 if wsb is None else wsb.numel() * 4, _st()),
+                                    0 if wsb is None else wsb.numel() * 4,
+                                    None if live is None else _p(live.quad_list), _st()),
               "gct_linear_fwd_p")
 
 
@@ -342,6 +348,18 @@ def nonzero_row_tiles(x2d: torch.Tensor):
     return lst, cnt
 
 
+_SKIPPED = {}
+
+
+def skipped_row_gradients():
+    """Device counter (int32[1], one per device) of gradient rows that fell on decoder rows a forward had skipped."""
+    dev = torch.cuda.current_device()
+    t = _SKIPPED.get(dev)
+    if t is None:
+        t = _SKIPPED[dev] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", dev))
+    return t
+
+
 class LiveRows:
     """Device-side description of the rows of a decoder gradient that are not identically zero, the check that makes
     shortcuts on them exact, and the compaction map of the decoder backward (csrc/liverows.hip).
@@ -350,6 +368,7 @@ class LiveRows:
       quad_list / cstart / n_b / Mc  (after host()): rows are compacted in aligned quads, compact row 4i+e <->
                   original row 4*quad_list[i]+e, Mc compact rows (multiple of 128)."""
     SLACK = 256        # rows behind Mc in every compact buffer: attention stages whole L-row windows of a sample
+    fwd = False        # True (instance): the FORWARD ran on these compact rows too (engine.decoder_trunk_fwd)
 
     def __init__(self, g2d, B, T, mask_u8, lists=True):
         _chk(g2d, "g2d")
@@ -378,12 +397,32 @@ class LiveRows:
         self._host = None
         self.Mc = None
 
+    @classmethod
+    def from_rows(cls, rows_u8, B, T, mask_u8):
+        """The same maps from a given row set (rows_u8 [B, T], non-zero = live) instead of from a gradient: the decoder
+        forward over the rows that reach the loss."""
+        _chk(rows_u8, "live_rows.rows", torch.uint8)
+        return cls(rows_u8.reshape(B * T, 1).to(torch.float32), B, T, mask_u8)
+
     def host(self):
         if self._host is None:
-            v = self.info.tolist()
+            v = torch.cat([self.info, skipped_row_gradients()]).tolist()          # ONE read-back
             self._host = dict(n_live=v[0], violations=v[1], nonprefix=v[2], tiles=v[3], padded=v[4], quads=v[5])
             self.Mc = v[4]
+            if v[8] != 0:
+                skipped_row_gradients().zero_()
+                raise _lib.GctError(
+                    f"{v[8]} decoder rows that an earlier forward skipped (loss_rows: rows that do not reach the loss) "
+                    "received a non-zero gradient in its backward pass: that gradient was ignored.  Call the model "
+                    "without loss_rows (forward_propagation(..., skip_ignored=False)) for losses other than the "
+                    "reference's ignore_index cross-entropy.")
         return self._host
+
+    def check_grad(self, g2d):
+        """The backward of a forward that ran on these rows only: count the gradient rows outside them that are not
+        zero (device counter, read at the next host() of any LiveRows -- no synchronisation here)."""
+        check(_L().gct_dead_rows_nonzero(_p(g2d), g2d.stride(0), self.M, g2d.shape[1], _p(self.live),
+                                         _p(skipped_row_gradients()), _st()), "gct_dead_rows_nonzero")
 
     def empty(self, cols):
         """A compact [Mc, cols] activation (with SLACK rows of allocation behind it)."""
@@ -529,18 +568,26 @@ def _tb(mb):
 
 
 def attn_fwd(q, k, v, ld_q, ld_k, ld_v, mask, B, H, Lq, Lk, dk, p, seed, site, out=None,
-             want_probs=False, keys=None):
+             want_probs=False, keys=None, live=None):
     """q/k/v: tensors whose data_ptr is element (b=0,l=0,h=0,0) with row strides ld_*.
-    mask: None | MaskBits | uint8 [B,Lk] / [B,1,Lk] (key padding) / [B,Lq,Lk] (packed on the fly)."""
+    mask: None | MaskBits | uint8 [B,Lk] / [B,1,Lk] (key padding) / [B,Lq,Lk] (packed on the fly).
+    live (LiveRows): q and the output hold the compact query rows only; keys (LiveRows / KeyRows): so do k / v."""
     dev = q.device
-    o = torch.empty(B * Lq, H * dk, dtype=torch.float32, device=dev) if out is None else out
+    if out is not None:
+        o = out
+    elif live is not None:     # rows of a live quad outside every sample's live prefix are not written: keep them finite
+        o = torch.zeros(live.Mc + live.SLACK, H * dk, dtype=torch.float32, device=dev)[:live.Mc]
+    else:
+        o = torch.empty(B * Lq, H * dk, dtype=torch.float32, device=dev)
     lse = torch.empty(B * H * Lq, dtype=torch.float32, device=dev)
     probs = torch.empty(B, H, Lq, Lk, dtype=torch.float32, device=dev) if want_probs else None
     mp, sb, sq, mask_owner = _mb(mask, B, Lq, Lk)
     check(_L().gct_attn_fwd(_p(q), ld_q, _p(k), ld_k, _p(v), ld_v, mp, sb, sq, _p(o),
                             o.stride(0), _p(lse), _p(probs), B, H, Lq, Lk, dk,
                             1.0 / math.sqrt(dk), p, seed, site, None if keys is None else _p(keys.cstart),
-                            None if keys is None else _p(keys.n_b), *_tb(mask_owner), _st()), "gct_attn_fwd")
+                            None if keys is None else _p(keys.n_b), *_tb(mask_owner),
+                            None if live is None else _p(live.cstart), None if live is None else _p(live.n_b),
+                            _st()), "gct_attn_fwd")
     del mask_owner
     return o, lse, probs
 
@@ -564,14 +611,16 @@ def _attn_bwd_ws(dev, nbytes):
 def attn_bwd(q, k, v, ld_q, ld_k, ld_v, mask, o, dout, lse, dq, dk_, dv, ld_dq, ld_dk, ld_dv,
              B, H, Lq, Lk, dk, p, seed, site, live=None, kv_compact=False, keys=None):
     """live (LiveRows): dout / dq are quad-compacted; kv_compact: so are dk / dv (self-attention); keys (KeyRows):
-    k / v / dk / dv hold the visible keys only (cross-attention)."""
+    k / v / dk / dv hold the visible keys only (cross-attention).  live.fwd: the forward ran on the compact rows, so
+    q and o are compact as well (and, for self-attention, k / v: pass keys=live, kv_compact=False)."""
     ws = _attn_bwd_ws(q.device, int(_L().gct_attn_bwd_ws_bytes(B, H, Lq, Lk)))
     mp, sb, sq, mask_owner = _mb(mask, B, Lq, Lk)
     check(_L().gct_attn_bwd(_p(q), ld_q, _p(k), ld_k, _p(v), ld_v, mp, sb, sq, _p(o),
                             _p(dout), o.stride(0), _p(lse), _p(dq), ld_dq, _p(dk_), ld_dk,
                             _p(dv), ld_dv, B, H, Lq, Lk, dk, 1.0 / math.sqrt(dk), p, seed, site,
                             None if live is None else _p(live.cstart), None if live is None else _p(live.n_b),
-                            int(bool(kv_compact)), None if keys is None else _p(keys.cstart),
+                            int(bool(kv_compact)) | (2 if (live is not None and live.fwd) else 0),
+                            None if keys is None else _p(keys.cstart),
                             None if keys is None else _p(keys.n_b), *_tb(mask_owner), _p(ws),
                             0 if ws is None else ws.numel(),
                             _st()), "gct_attn_bwd")

@@ -37,7 +37,7 @@ extern "C" {
 #define GCT_ERR_ARG (-1)  /* bad shape / alignment / null pointer            */
 #define GCT_ERR_HIP (-2)  /* a HIP runtime call failed (launch error)        */
 
-#define GCT_ABI_VERSION 9
+#define GCT_ABI_VERSION 10
 
 int gct_version(void);
 const char* gct_last_error(void);
@@ -164,7 +164,10 @@ int gct_linear_fwd_p(const float* x, int64_t ldx, int64_t M, int K,
                      const float* b0, const float* b1, const float* b2,
                      int nseg, int nper, float* y0, float* y1, float* y2, int64_t ldy,
                      int epi, const float* resid, float* pre, float p, uint64_t seed, uint32_t site,
-                     float* ws, int64_t ws_bytes, void* stream);
+                     float* ws, int64_t ws_bytes, const int32_t* quad_map, void* stream);
+/* quad_map of gct_linear_fwd_p (nullable): the M rows are a quad compaction of a larger row space (gct_live_rows); the
+ * dropout masks of the GCT_EPI_GELU_DROP / GCT_EPI_DROP_RESID epilogues are then drawn at the coordinates of original quad
+ * quad_map[q] for compact quad q, i.e. every live row gets exactly the mask it would get in the full row space. */
 int gct_linear_dgrad_p(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
                        int64_t M, int nseg, int nper,
                        const float* w0, const float* w1, const float* w2, int64_t ldw,
@@ -186,6 +189,11 @@ int64_t gct_linear_dgrad_ws_bytes(int64_t M, int Ntot, int K);
  * flags_ws: >= ceil(rows/32) bytes); gct_linear_wgrad_kt is gct_linear_wgrad reducing only over the listed
  * token tiles -- exact whenever every dy row outside them is zero (the skipped terms are 0 * x).  The list is
  * honoured by the bf16x6 kernel; the fp32 kernels reduce over all rows (same result). */
+/* *counter += number of rows of g[rows][cols] with live[row] == 0 that hold a non-zero element: the check a forward
+ * that SKIPPED the dead rows (decoder forward over the rows that reach the loss) owes its backward -- a gradient on a
+ * skipped row cannot be honoured.  The caller reads the counter at its next host synchronisation. */
+int gct_dead_rows_nonzero(const float* g, int64_t ld, int64_t rows, int cols, const uint8_t* live,
+                          int32_t* counter, void* stream);
 int gct_nonzero_row_tiles(const float* x, int64_t ld, int64_t rows, int cols, int32_t* list,
                           int32_t* count, uint8_t* flags_ws, void* stream);
 /* The property above holds only if no live query row attends to a dead (zero-gradient) row: a dead row that is a
@@ -253,13 +261,19 @@ int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const
                  int64_t ldv, const uint32_t* mbits, int64_t mb_sb, int64_t mb_sq,
                  float* o, int64_t ldo, float* lse, float* probs, int B, int H, int Lq, int Lk,
                  int dk, float scale, float p, uint64_t seed, uint32_t site, const int32_t* kstart,
-                 const int32_t* klen, const uint32_t* tbits, int64_t tb_sb, int64_t tb_su, void* stream);
+                 const int32_t* klen, const uint32_t* tbits, int64_t tb_sb, int64_t tb_su,
+                 const int32_t* qstart, const int32_t* qlen, void* stream);
 /* kstart / klen (nullable, together; gct_key_rows): k and v hold only the VISIBLE keys of every sample, quad-compacted:
- * the rows of sample b start at kstart[b] and there are klen[b] of them (keys klen[b]..Lk-1 are masked by mbits). */
+ * the rows of sample b start at kstart[b] and there are klen[b] of them (keys klen[b]..Lk-1 are masked by mbits).
+ * qstart / qlen (nullable, together; gct_live_rows): q and o hold only the first qlen[b] query rows of sample b, at rows
+ * qstart[b].. (the decoder forward over the rows that reach the loss); lse keeps its [B][H][Lq] layout, entries of rows
+ * that do not exist are not written.  Needs the direct kernels (Lk <= 96, probs == NULL). */
 /* dq/dk/dv written (overwrite) with the same layout as q/k/v.
  * cstart / nlive (nullable, together): dout and dq are quad-compacted (gct_live_rows): the rows of sample b start at
- * cstart[b] and only its first nlive[b] query rows exist; kv_compact != 0 (self-attention, Lq == Lk): dk / dv live
- * in those compact rows too.  q, k, v, o, lse stay in the forward's layout. */
+ * cstart[b] and only its first nlive[b] query rows exist; kv_compact bit 0 (self-attention, Lq == Lk): dk / dv live
+ * in those compact rows too while q, k, v, o stay in the forward's layout; kv_compact bit 1: q and o are compact like
+ * dout / dq (the forward ran with qstart / qlen; pass kstart / klen = cstart / nlive for self-attention) -- direct
+ * kernels only.  lse keeps the forward's layout. */
 int gct_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
                  int64_t ldv, const uint32_t* mbits, int64_t mb_sb, int64_t mb_sq,
                  const float* o, const float* dout, int64_t ldo, const float* lse,

@@ -613,6 +613,115 @@ def test_compacted_decoder_backward_matches_dense(mtype, kw, B, S, p, monkeypatc
         assert_close(grads[True][n], e, 2e-6 * float(e.abs().max()) + floor, 2e-5, f"compact vs dense: {n}")
 
 
+def _fwd_loss_skip(model, mtype, batch, beta, skip):
+    from gct_plus_amd.Model import forward_propagation
+    from gct_plus_amd.Train.trainer1 import loss_function
+    b = to_dev(batch)
+    prop, mol, mu, lv, z = forward_propagation[mtype](model, b, PAD, False, skip_ignored=skip)
+    ys = b["trg"][:, 1:].contiguous().view(-1)
+    nc = synthetic.n_conds(mtype)
+    ys_cond = b["dconds"].unsqueeze(2).contiguous().view(-1, nc, 1) if nc else None
+    loss = loss_function(beta, prop, mol, ys_cond, ys, mu, lv, False, PAD)[0]
+    return mol, loss
+
+
+@pytest.mark.parametrize("mtype,kw,B,S,p", [("pscavaetf", {}, 9, 70, 0.0), ("pvaetf", {}, 16, 77, 0.2),
+                                            ("scavaetf", {}, 12, 60, 0.1),
+                                            ("vaetf", dict(N=2, d_model=512, dff=2048, h=8, latent_dim=128), 48, 80, 0.1)])
+def test_decoder_forward_over_loss_rows_matches_dense(mtype, kw, B, S, p, monkeypatch):
+    """forward_propagation(..., skip_ignored=True) -- the trainer's mode: the decoder forward AND backward run on the
+    quad-compacted rows whose logits reach the ignore_index loss (engine.decoder_trunk_fwd(loss_rows=...)) -- against
+    the dense model on the same inputs, seeds and dropout masks: the loss, every parameter gradient, the logits of the
+    rows the loss reads; the skipped rows come back as out.bias (decoder output zero).  The dropout cases prove that
+    every dropout site of the compact forward (GEMM epilogues, attention) draws the bits of the ORIGINAL coordinates."""
+    from gct_plus_amd import engine
+    ds = synthetic.make_dataset(B, S, mtype, seed=31)
+    nc = synthetic.n_conds(mtype)
+    eps = torch.randn(B, S + nc, kw.get("latent_dim", TINY["latent_dim"]), generator=torch.Generator().manual_seed(2))
+    res, took = {}, {}
+    for skip in (True, False):
+        seen = []
+        real = engine.ops.LiveRows.scatter
+        monkeypatch.setattr(engine.ops.LiveRows, "scatter", lambda self, *a, **k: (seen.append(self.fwd), real(self, *a, **k))[1])
+        torch.manual_seed(77)
+        engine._SEED["base"] = None                      # same dropout seeds in both runs
+        model = build(mtype, dropout=p, seed=5, **kw).train()
+        set_eps(model, eps)
+        mol, loss = _fwd_loss_skip(model, mtype, ds, 0.04, skip)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[skip] = {n: q.grad.detach().clone() for n, q in model.named_parameters() if q.grad is not None}
+        res[skip]["__loss__"] = loss.detach().reshape(1).clone()
+        res[skip]["__logits__"] = mol.detach().clone()
+        res[skip]["__bias__"] = model.out.bias.detach().clone()
+        took[skip] = [f for f in seen if f]
+        monkeypatch.setattr(engine.ops.LiveRows, "scatter", real)
+    assert len(took[True]) >= 2 and not took[False]      # forward and backward both ran on the forward's compact rows
+    keep = (ds["trg"][:, 1:] != PAD).cuda()
+    lt, lf = res[True].pop("__logits__"), res[False].pop("__logits__")
+    assert_close(lt[keep], lf[keep], 1e-5, 1e-5, "logits of the rows the loss reads")
+    bias = res[True].pop("__bias__")
+    res[False].pop("__bias__")
+    # skipped rows: W . 0 + b -- except the (at most 3 + 3 per sample) padded rows that share an aligned group of four
+    # rows with a live one: those travel with their quad and hold finite, meaningless values
+    flat_keep = keep.reshape(-1)
+    quads = torch.nn.functional.pad(flat_keep, (0, (-flat_keep.numel()) % 4)).view(-1, 4).any(1)
+    in_live_quad = quads.repeat_interleave(4)[:flat_keep.numel()].view_as(keep)
+    assert torch.equal(lt[~in_live_quad], bias.expand_as(lt)[~in_live_quad])
+    assert torch.isfinite(lt).all()
+    floor = grad_floor(list(res[False].values()))
+    for n, e in res[False].items():
+        assert_close(res[True][n], e, 2e-6 * float(e.abs().max()) + floor, 2e-5, f"loss-row forward vs dense: {n}")
+
+
+def test_full_size_batch_512_skip_ignored_vs_oracle():
+    """BASELINE configs[1] in the TRAINER's mode (skip_ignored=True: what bench.py times): loss and every gradient
+    against the CPU oracle, logits on the rows the loss reads."""
+    from oracle import gct_oracle as O
+    mtype, B = "vaetf", 512
+    model = build(mtype, full=True).train()
+    vs, vt = synthetic.vocab_sizes(mtype)
+    cfg = O.make_cfg(mtype, vs, vt, dropout=0.0, nconds=0, use_cond2lat=True)
+    P = O.make_leaves({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    ds = synthetic.make_dataset(B, max_len=80, model_type=mtype, seed=0)
+    eps = torch.randn(B, 80, 128, generator=torch.Generator().manual_seed(23))
+    set_eps(model, eps)
+    mol, loss = _fwd_loss_skip(model, mtype, ds, 0.04, True)
+    sm, tm, trg_in = O.batch_masks(cfg, ds, PAD)
+    _, omol, omu, olv, oz = O.forward(P, cfg, ds["src"], trg_in, sm, tm, eps=eps, train=True)
+    keep = ds["trg"][:, 1:] != PAD
+    assert_close(mol.detach().cpu()[keep], omol.detach()[keep], 1e-4, 1e-4, "logits (loss rows)")
+    ys = ds["trg"][:, 1:].contiguous().view(-1)
+    oloss, _, _, _ = O.loss_function(0.04, None, omol, None, ys, omu, olv, False, PAD)
+    assert abs(loss.item() - oloss.item()) <= 2e-5 * abs(oloss.item())
+    loss.backward()
+    oloss.backward()
+    floor = grad_floor(v.grad for v in P.values())
+    for name, p in model.named_parameters():
+        if P[name].grad is None:
+            continue
+        e = P[name].grad
+        assert_close(p.grad, e, 2e-5 * float(e.abs().max()) + floor, 1e-3, "grad " + name)
+
+
+def test_gradient_on_a_skipped_row_is_reported():
+    """A forward that skipped decoder rows cannot honour a gradient on them: the backward counts such rows on the device
+    and the next read-back (the next forward's row maps) raises instead of training on a silently wrong gradient."""
+    from gct_plus_amd import _lib, ops
+    mtype = "vaetf"
+    model = build(mtype).train()
+    ds = synthetic.make_dataset(16, 60, mtype, seed=3)     # large enough for the compact forward to be taken
+    ops.skipped_row_gradients().zero_()
+    mol, _ = _fwd_loss_skip(model, mtype, ds, 0.04, True)
+    mol.sum().backward()                                  # a loss that reads EVERY row, unlike the ignore_index CE
+    with pytest.raises(_lib.GctError, match="skipped"):
+        _fwd_loss_skip(model, mtype, ds, 0.04, True)
+    assert int(ops.skipped_row_gradients().item()) == 0   # reported once, then cleared
+    mol, loss = _fwd_loss_skip(model, mtype, ds, 0.04, True)
+    loss.backward()
+    _fwd_loss_skip(model, mtype, ds, 0.04, True)          # the reference's loss: nothing to report
+
+
 def test_greedy_decode_token_ids_bit_exact(golden_dir):
     """G5: argmax-decoded ids from model.decode equal the reference's."""
     from gct_plus_amd.Model import get_trg_mask

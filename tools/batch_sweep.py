@@ -1,5 +1,5 @@
 """Robustness sweep over batch sizes and model types: three training steps (dropout 0.1, Adam) with the data-dependent
-shortcuts on (compacted decoder backward, visible-rows cross-attention K/V, tail balancing as the sizes fall) and
+shortcuts on (decoder forward and backward over the live rows, visible-rows cross-attention K/V, tail balancing as the sizes fall) and
 again with them off; the per-step losses must agree (the shortcuts are exact: same arithmetic on the live rows, same
 dropout bits; only summation splits differ).  python tools/batch_sweep.py [--batches 24,64,...]"""
 import argparse, sys, torch
@@ -15,7 +15,7 @@ DIMS = dict(N=6, d_model=512, dff=2048, h=8, latent_dim=128)
 
 
 def run(mtype, B, compact, S=80):
-    engine.COMPACT_BWD = engine.COMPACT_KV = compact
+    engine.COMPACT_BWD = engine.COMPACT_KV = engine.COMPACT_FWD = compact
     engine._SEED.update(base=None, ctr=0)          # same dropout / eps streams in both runs
     vs, vt = synthetic.vocab_sizes(mtype)
     nc = synthetic.n_conds(mtype)
@@ -28,7 +28,7 @@ def run(mtype, B, compact, S=80):
     torch.manual_seed(7)
     for batch in synthetic.batches(ds, B):
         batch = {k: v.to(dev) for k, v in batch.items()}
-        prop, mol, mu, lv, _ = forward_propagation[mtype](model, batch, synthetic.PAD_ID, False)
+        prop, mol, mu, lv, _ = forward_propagation[mtype](model, batch, synthetic.PAD_ID, False, skip_ignored=True)
         ys = batch["trg"][:, 1:].contiguous().view(-1)
         ys_cond = batch["dconds"].unsqueeze(2).contiguous().view(-1, nc, 1) if nc else None
         loss, _, _, _ = loss_function(0.04, prop, mol, ys_cond, ys, mu, lv, False, synthetic.PAD_ID)
