@@ -66,14 +66,21 @@ class Decoder(nn.Module, _TrunkParams):
         self.layers = get_clones(DecoderLayer(h, d_model, dff, dropout, get_attn), N)
         self.norm = Norm(d_model)
 
-    def forward(self, trg, z, src_mask, trg_mask, dconds=None, loss_rows=None):
+    def forward(self, trg, z, src_mask, trg_mask, dconds=None, loss_rows=None, _compact_out=False):
         """loss_rows: see Model/vaetf.py Decoder.forward (an extension of this build)."""
         run = engine.Run(self.p, self.training)
         if loss_rows is not None:
             loss_rows = loss_rows.to(torch.uint8).contiguous()
+        self._gct_live_out = None
         outs = engine.DecoderFn.apply(self, run, trg.contiguous(), z, ops.to_mask_u8(src_mask),
                                       ops.to_mask_u8(trg_mask), dconds, self.get_attn, loss_rows,
                                       *self.trunk_params())
+        if self._gct_live_out is not None and not _compact_out:
+            # the trunk ran on the loss rows only and returned them compact [Mc, d]: a caller of the decoder alone gets
+            # every row (zeros where nothing was computed); Vaetf / Cvaetf.forward keep the compact rows through the
+            # vocabulary head and scatter the logits instead
+            live, self._gct_live_out = self._gct_live_out, None
+            outs = engine.ScatterRowsFn.apply(outs, live, trg.size(0), trg.size(1))
         if self.get_attn:
             n = self.N
             return outs[0], list(outs[1:1 + n]), list(outs[1 + n:1 + 2 * n])
@@ -118,10 +125,14 @@ class Cvaetf(FlatModelMixin, nn.Module):
         z, mu, log_var = self.encoder(src, src_mask, econds)[:3]
         if self.get_attn or (self.use_cond2dec and self.nconds > 0):
             loss_rows = None
-        d_output = self.decoder(trg, z, src_mask, trg_mask, dconds, loss_rows)
+        d_output = self.decoder(trg, z, src_mask, trg_mask, dconds, loss_rows, _compact_out=True)
         if self.get_attn:
             d_output = d_output[0]
         output = self.out(d_output)
+        live = self.decoder._gct_live_out
+        if live is not None:            # the decoder ran on the loss rows only: d_output and the logits are compact [Mc, .]
+            self.decoder._gct_live_out = None
+            output = engine.ScatterRowsFn.apply(output, live, trg.size(0), trg.size(1))
         if self.use_cond2dec and self.nconds > 0:
             output_prop = self.prop_fc(output[:, :self.nconds, :])
             output_mol = output[:, self.nconds:, :]

@@ -76,15 +76,22 @@ class Decoder(nn.Module, _TrunkParams):
         if use_cond2lat and nconds > 0:
             self.embed_cond2lat = nn.Linear(nconds, d_model * nconds)
 
-    def forward(self, trg, z, src_mask, trg_mask, dconds, loss_rows=None):
+    def forward(self, trg, z, src_mask, trg_mask, dconds, loss_rows=None, _compact_out=False):
         """loss_rows (bool / uint8 [B, T], optional -- an extension of this build): the rows whose output reaches the
         loss; the others are not computed and come back as zeros (engine.decoder_trunk_fwd)."""
         run = engine.Run(self.p, self.training)
         if loss_rows is not None:
             loss_rows = loss_rows.to(torch.uint8).contiguous()
+        self._gct_live_out = None
         outs = engine.DecoderFn.apply(self, run, trg.contiguous(), z, ops.to_mask_u8(src_mask),
                                       ops.to_mask_u8(trg_mask), dconds, self.get_attn, loss_rows,
                                       *self.trunk_params())
+        if self._gct_live_out is not None and not _compact_out:
+            # the trunk ran on the loss rows only and returned them compact [Mc, d]: a caller of the decoder alone gets
+            # every row (zeros where nothing was computed); Vaetf / Cvaetf.forward keep the compact rows through the
+            # vocabulary head and scatter the logits instead
+            live, self._gct_live_out = self._gct_live_out, None
+            outs = engine.ScatterRowsFn.apply(outs, live, trg.size(0), trg.size(1))
         if self.get_attn:
             n = self.N
             return outs[0], list(outs[1:1 + n]), list(outs[1 + n:1 + 2 * n])
@@ -136,16 +143,19 @@ class Vaetf(FlatModelMixin, nn.Module):
     def forward(self, src, trg, src_mask, trg_mask, econds=None, dconds=None, *, loss_rows=None):
         """Reference signature (Model/vaetf.py:154) plus one keyword-only extension: loss_rows (bool [B, T]) names the
         decoder rows whose logits reach the loss -- the trainer passes `ys != pad` (Model/forward_propagation1.py); the
-        other rows are then not computed at all and their logits come back as `out.bias` (the decoder output is zero
-        there), NOT as the reference's values.  Default (None): every row, as the reference."""
+        other rows are then not computed at all and their logits come back as zeros, NOT as the reference's values.  Default (None): every row, as the reference."""
         x, enc_attn = self.encoder.trunk(src, src_mask, econds)
         z, mu, log_var = self.sampler(x)
         if self.get_attn or (self.use_cond2dec and self.nconds > 0):
             loss_rows = None
-        d = self.decoder(trg, z, src_mask, trg_mask, dconds, loss_rows)
+        d = self.decoder(trg, z, src_mask, trg_mask, dconds, loss_rows, _compact_out=True)
         if self.get_attn:
             d, dec_attn_1, dec_attn_2 = d
         output = self.out(d)
+        live = self.decoder._gct_live_out
+        if live is not None:            # the decoder ran on the loss rows only: d and the logits are compact [Mc, .]
+            self.decoder._gct_live_out = None
+            output = engine.ScatterRowsFn.apply(output, live, trg.size(0), trg.size(1))
         if self.use_cond2dec:
             output_prop = self.prop_fc(output[:, :self.nconds, :])
             output_mol = output[:, self.nconds:, :]

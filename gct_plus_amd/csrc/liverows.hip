@@ -178,6 +178,33 @@ __global__ __launch_bounds__(256) void scatter_quads_kernel(const float* __restr
   }
 }
 
+// the same two maps for any column count / alignment (the vocabulary head's 28-31 logits per row): one element per thread
+__global__ __launch_bounds__(256) void gather_quads_scalar_kernel(const float* __restrict__ src, int64_t ld, int64_t M,
+                                                                  const int32_t* __restrict__ quad_list, int64_t nrows,
+                                                                  int cols, float* __restrict__ dst, int64_t ldd) {
+  const int64_t total = nrows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / cols;
+    const int c = (int)(i - row * cols);
+    const int q = quad_list[row >> 2];
+    const int64_t r = (int64_t)q * 4 + (row & 3);
+    dst[row * ldd + c] = (q >= 0 && r < M) ? src[r * ld + c] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void scatter_quads_scalar_kernel(const float* __restrict__ src, int64_t ld,
+                                                                   const int32_t* __restrict__ quad_list, int64_t nrows,
+                                                                   int cols, float* __restrict__ dst, int64_t ldd,
+                                                                   int64_t M) {
+  const int64_t total = nrows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / cols;
+    const int c = (int)(i - row * cols);
+    const int q = quad_list[row >> 2];
+    const int64_t r = (int64_t)q * 4 + (row & 3);
+    if (q >= 0 && r < M) dst[r * ldd + c] = src[row * ld + c];
+  }
+}
+
 // flags[t] = 32-row tile t holds a live row, or the dead-key check failed (then every tile is listed)
 __global__ __launch_bounds__(256) void live_tile_flags_kernel(const uint8_t* __restrict__ live, int64_t rows,
                                                               const int32_t* __restrict__ info,
@@ -339,10 +366,17 @@ extern "C" int gct_key_rows(const uint8_t* mask, int64_t mask_sb, int B, int Lk,
 
 extern "C" int gct_gather_quads(const float* src, int64_t ld, int64_t M, const int32_t* quad_list, int64_t nrows,
                                 int cols, float* dst, int64_t ldd, void* stream) {
-  GCT_CHECK_ARG(src && quad_list && dst && nrows >= 0 && nrows % 4 == 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 &&
-                    ldd % 4 == 0 && gct_aligned16(src) && gct_aligned16(dst),
+  GCT_CHECK_ARG(src && quad_list && dst && nrows >= 0 && nrows % 4 == 0 && cols > 0 && ld >= cols && ldd >= cols,
                 "gather_quads: bad args");
   if (nrows == 0) return GCT_OK;
+  if (cols % 4 != 0 || ld % 4 != 0 || ldd % 4 != 0 || !gct_aligned16(src) || !gct_aligned16(dst)) {
+    int64_t gs = (nrows * cols + 255) / 256;
+    if (gs > 8192) gs = 8192;
+    hipLaunchKernelGGL(gather_quads_scalar_kernel, dim3((unsigned)gs), dim3(256), 0, (hipStream_t)stream, src, ld, M,
+                       quad_list, nrows, cols, dst, ldd);
+    GCT_LAUNCH_CHECK("gather_quads (scalar)");
+    return GCT_OK;
+  }
   const int64_t work = nrows * (cols / 4);
   int64_t grid = (work + 255) / 256;
   if (grid > 8192) grid = 8192;
@@ -354,10 +388,17 @@ extern "C" int gct_gather_quads(const float* src, int64_t ld, int64_t M, const i
 
 extern "C" int gct_scatter_quads(const float* src, int64_t ld, const int32_t* quad_list, int64_t nrows, int cols,
                                  float* dst, int64_t ldd, int64_t M, void* stream) {
-  GCT_CHECK_ARG(src && quad_list && dst && nrows >= 0 && nrows % 4 == 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 &&
-                    ldd % 4 == 0 && gct_aligned16(src) && gct_aligned16(dst),
+  GCT_CHECK_ARG(src && quad_list && dst && nrows >= 0 && nrows % 4 == 0 && cols > 0 && ld >= cols && ldd >= cols,
                 "scatter_quads: bad args");
   if (nrows == 0) return GCT_OK;
+  if (cols % 4 != 0 || ld % 4 != 0 || ldd % 4 != 0 || !gct_aligned16(src) || !gct_aligned16(dst)) {
+    int64_t gs = (nrows * cols + 255) / 256;
+    if (gs > 8192) gs = 8192;
+    hipLaunchKernelGGL(scatter_quads_scalar_kernel, dim3((unsigned)gs), dim3(256), 0, (hipStream_t)stream, src, ld,
+                       quad_list, nrows, cols, dst, ldd, M);
+    GCT_LAUNCH_CHECK("scatter_quads (scalar)");
+    return GCT_OK;
+  }
   const int64_t work = nrows * (cols / 4);
   int64_t grid = (work + 255) / 256;
   if (grid > 8192) grid = 8192;

@@ -387,10 +387,12 @@ def decoder_trunk_fwd(dec, run: Run, trg, z, src_mask_u8, trg_mask_u8, dconds, w
     the set influences a row inside it only as a KEY of self-attention, so when no live query can see a dead row under
     THIS call's trg_mask (checked on the device, as for the compacted backward) the whole trunk runs on the quad-
     compacted live rows: every GEMM, Norm and attention launch sees ~half the rows, every dropout site draws the bits of
-    the original coordinates, the backward finds its activations compact already.  The returned tensor has all B*T
-    rows; the skipped ones are ZERO -- or, for the few padded rows that share an aligned group of four rows with a live
-    one, finite values without meaning -- not the reference's values (nothing downstream of an ignore_index loss reads
-    them), and a gradient that arrives on a skipped row is reported as an error (ops.LiveRows.check_grad)."""
+    the original coordinates, the backward finds its activations compact already.  When the shortcut is taken the trunk
+    RETURNS THE COMPACT ROWS [Mc, d] and the map (saved[-1]); whoever scatters them back (ScatterRowsFn: Decoder.forward
+    for a caller of the decoder alone, Vaetf / Cvaetf.forward behind the vocabulary head) produces zeros on the skipped
+    rows -- or, for the few padded rows that share an aligned group of four rows with a live one, finite values without
+    meaning -- not the reference's values (nothing downstream of an ignore_index loss reads them), and reports a
+    gradient that arrives on a skipped row as an error (ops.LiveRows.check_grad)."""
     B, T0 = trg.shape
     d, nc = dec.d_model, dec.nconds
     Le, lat = z.shape[1], z.shape[2]
@@ -457,10 +459,10 @@ def decoder_trunk_fwd(dec, run: Run, trg, z, src_mask_u8, trg_mask_u8, dconds, w
         p1s.append(p1)
         p2s.append(p2)
     y, mean, rstd = ops.norm_fwd(x, dec.norm.alpha, dec.norm.bias, dec.norm.eps)
-    if live is not None:
-        y = live.scatter(y)                               # [B*T, d]: zero rows where the loss does not look
     saved = (trg, z2, dconds, site_pe, lsv, x, mean, rstd, B, T, Le, Lk, c2d, c2l,
              trg_mask_u8.u8 if isinstance(trg_mask_u8, ops.MaskBits) else trg_mask_u8, keys, live)
+    if live is not None:
+        return y, saved, p1s, p2s        # [Mc, d] COMPACT rows: the caller owns `saved[-1]` (the map) and scatters what it needs
     return y.view(B, T, d), saved, p1s, p2s
 
 
@@ -476,23 +478,22 @@ def decoder_trunk_bwd(dec, run: Run, saved, dy, G: GradSink, need_dz=True):
     # (csrc/liverows.hip).  When it holds (and pays), the whole decoder backward runs on the QUAD-COMPACTED live
     # rows: every GEMM, norm and dropout backward sees ~half the rows; otherwise the dense path runs, with the
     # weight-gradient GEMMs reducing over the live token tiles (the list names every tile when the check fails).
-    g = dy.reshape(B * T, d)
     live = None
     if live_fwd is not None:
-        # the forward ran on these rows only: the backward runs on the same compact rows (what the forward saved is
-        # compact), and a gradient on a row it skipped cannot be honoured -- counted on the device, raised at the
-        # next read-back (no synchronisation here)
+        # the forward ran on these rows only and handed out COMPACT rows: dy arrives compact (ScatterRowsFn gathers the
+        # gradient of what it scattered and reports gradient rows that fell on skipped rows)
         live = live_fwd
-        live.check_grad(g)
         lr = None
+        g = dy.reshape(live.Mc, d)
     else:
+        g = dy.reshape(B * T, d)
         lr = ops.LiveRows(g, B, T, trg_mask_u8) if (COMPACT_BWD or (B * T) % 32 == 0) else None
     if live is None and COMPACT_BWD and lr is not None and len(dec.layers) > 0 and not torch.cuda.is_current_stream_capturing():
         h = lr.host()                                   # one 32-byte read-back per step
         if h["violations"] == 0 and h["nonprefix"] == 0 and 0 < h["padded"] <= COMPACT_MAX_FRACTION * B * T:
             live = lr
     if live is not None:
-        gc = live.gather(g)
+        gc = g.clone() if live_fwd is not None else live.gather(g)
         gdbuf = live.empty(d) if run.p > 0 else None
         dr = _ffn_drop(run, lsv[-1][-1], gdbuf)
         ops.norm_bwd(gc, x_last, dec.norm.alpha, mean, rstd, G(dec.norm.alpha), G(dec.norm.bias), out=gc,
@@ -575,6 +576,8 @@ class DecoderFn(torch.autograd.Function):
         y, saved, p1, p2 = decoder_trunk_fwd(dec, run, trg, _f32c(z), src_mask_u8, trg_mask_u8,
                                              dconds, want_probs, loss_rows=loss_rows)
         ctx.dec, ctx.run, ctx.saved, ctx.params = dec, run, saved, params
+        dec._gct_live_out = saved[-1]          # not None: y holds the COMPACT live rows [Mc, d] (Decoder.forward hands
+                                               # the map to its caller, who scatters what it needs: ScatterRowsFn)
         ctx.need_dz = z.requires_grad
         if want_probs:
             for p in p1 + p2:
@@ -588,6 +591,24 @@ class DecoderFn(torch.autograd.Function):
         dz = decoder_trunk_bwd(ctx.dec, ctx.run, ctx.saved, _f32c(dy), G, ctx.need_dz)
         ctx.saved = None
         return (None, None, None, dz, None, None, None, None, None) + G.collect(ctx.params)
+
+
+class ScatterRowsFn(torch.autograd.Function):
+    """Compact rows [Mc, cols] of a decoder forward that ran on the loss rows only -> all [B, T, cols] rows (zeros where
+    nothing was computed).  Backward: the gradient's compact rows; gradient rows that fall on SKIPPED rows cannot be
+    honoured -- they are counted on the device and raised at the next read-back (ops.LiveRows.check_grad)."""
+
+    @staticmethod
+    def forward(ctx, xc, live, B, T):
+        ctx.live, ctx.shape = live, xc.shape
+        return live.scatter(_f32c(xc)).view(B, T, xc.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        live = ctx.live
+        g = _f32c(dy).reshape(live.M, dy.shape[-1])
+        live.check_grad(g)
+        return live.gather(g).view(ctx.shape), None, None, None
 
 
 class SamplerFn(torch.autograd.Function):

@@ -101,15 +101,17 @@ class FlatModelMixin:
         ops.register_planes(f["params"], f["planes"])
 
     def weights_token(self):
-        """Changes whenever the weights may have changed: (raw-write epoch, version counter of the flat parameter
-        buffer, its address).  Every torch in-place operation on a parameter bumps the version counter its view shares
-        with the flat buffer (load_state_dict, copy_, DDP-style broadcasts); the one writer that goes behind torch's
+        """Changes whenever the weights may have changed: (raw-write epoch, version counters of the flat buffer and of
+        every parameter, the buffer's address).  A torch in-place operation bumps the counter of the tensor it is applied
+        to -- a parameter (p.mul_, load_state_dict's copy_: the parameter's own counter, `p.data = view` does not share
+        the buffer's) or the flat buffer itself (the data-parallel broadcast); the one writer that goes behind torch's
         back -- FusedAdam's kernel -- reports through invalidate_weight_planes(), which bumps the epoch.  Caches of
         anything derived from the weights alone (decode.KVDecoder's folded cross-attention projections) key on it."""
         f = self._gct_flat
         if f is None:
             return None
-        return (getattr(self, "_gct_epoch", 0), f["params"]._version, f["params"].data_ptr())
+        return (getattr(self, "_gct_epoch", 0), f["params"]._version, f["params"].data_ptr(),
+                tuple(p._version for p in f["order"]))
 
     def invalidate_weight_planes(self):
         """Called by whoever rewrites the weights behind autograd's back (FusedAdam): GEMMs fall back

@@ -43,7 +43,11 @@ def run(mtype, B, compact, S=80):
 
 def compare(mtype, B, S=80):
     """max relative difference of the three per-sample losses, shortcuts on vs off"""
-    on, off = run(mtype, B, True, S), run(mtype, B, False, S)
+    keep = (engine.COMPACT_BWD, engine.COMPACT_KV, engine.COMPACT_FWD)
+    try:
+        on, off = run(mtype, B, True, S), run(mtype, B, False, S)
+    finally:
+        engine.COMPACT_BWD, engine.COMPACT_KV, engine.COMPACT_FWD = keep     # module state: leave it as it was found
     assert all(x == x for x in on + off), (mtype, B, on, off)
     return max(abs(x - y) / max(abs(y), 1e-9) for x, y in zip(on, off)), on, off
 
