@@ -9,7 +9,7 @@ from .. import engine, ops
 from ..flat import FlatModelMixin, planes_scope
 from .layers import DecoderLayer, EncoderLayer
 from .modules import Embeddings, Norm, PositionalEncoding, get_clones
-from .vaetf import Linear, _TrunkParams
+from .vaetf import Linear, _TrunkParams, _row_plan
 
 
 class Encoder(nn.Module, _TrunkParams):
@@ -31,10 +31,10 @@ class Encoder(nn.Module, _TrunkParams):
         self.eps_mode = "device"
         self.eps_override = None
 
-    def forward(self, src, src_mask, econds=None, eps=None):
+    def forward(self, src, src_mask, econds=None, eps=None, _keys=None):
         run = engine.Run(self.p, self.training)
         outs = engine.EncoderFn.apply(self, run, src.contiguous(), ops.to_mask_u8(src_mask), econds,
-                                      self.get_attn, *self.trunk_params())
+                                      self.get_attn, _keys, *self.trunk_params())
         x = outs[0] if self.get_attn else outs
         if eps is None and self.eps_override is not None:
             eps = self.eps_override.to(x.device)
@@ -66,14 +66,14 @@ class Decoder(nn.Module, _TrunkParams):
         self.layers = get_clones(DecoderLayer(h, d_model, dff, dropout, get_attn), N)
         self.norm = Norm(d_model)
 
-    def forward(self, trg, z, src_mask, trg_mask, dconds=None, loss_rows=None, _compact_out=False):
+    def forward(self, trg, z, src_mask, trg_mask, dconds=None, loss_rows=None, _compact_out=False, _plan=None):
         """loss_rows: see Model/vaetf.py Decoder.forward (an extension of this build)."""
         run = engine.Run(self.p, self.training)
         if loss_rows is not None:
             loss_rows = loss_rows.to(torch.uint8).contiguous()
         self._gct_live_out = None
         outs = engine.DecoderFn.apply(self, run, trg.contiguous(), z, ops.to_mask_u8(src_mask),
-                                      ops.to_mask_u8(trg_mask), dconds, self.get_attn, loss_rows,
+                                      ops.to_mask_u8(trg_mask), dconds, self.get_attn, loss_rows, _plan,
                                       *self.trunk_params())
         if self._gct_live_out is not None and not _compact_out:
             # the trunk ran on the loss rows only and returned them compact [Mc, d]: a caller of the decoder alone gets
@@ -122,10 +122,11 @@ class Cvaetf(FlatModelMixin, nn.Module):
     @planes_scope
     def forward(self, src, trg, src_mask, trg_mask, econds=None, dconds=None, *, loss_rows=None):
         """Reference signature (Model/cvaetf.py:179) plus the keyword-only loss_rows extension of Vaetf.forward."""
-        z, mu, log_var = self.encoder(src, src_mask, econds)[:3]
         if self.get_attn or (self.use_cond2dec and self.nconds > 0):
             loss_rows = None
-        d_output = self.decoder(trg, z, src_mask, trg_mask, dconds, loss_rows, _compact_out=True)
+        plan = _row_plan(self, src_mask, trg_mask, loss_rows, trg)
+        z, mu, log_var = self.encoder(src, src_mask, econds, _keys=plan.enc_keys)[:3]
+        d_output = self.decoder(trg, z, src_mask, trg_mask, dconds, loss_rows, _compact_out=True, _plan=plan)
         if self.get_attn:
             d_output = d_output[0]
         output = self.out(d_output)

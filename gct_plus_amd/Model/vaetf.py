@@ -45,10 +45,10 @@ class Encoder(nn.Module, _TrunkParams):
         if nconds > 0:
             self.embed_cond2enc = nn.Linear(nconds, d_model * nconds)
 
-    def trunk(self, src, src_mask, econds):
+    def trunk(self, src, src_mask, econds, _keys=None):
         run = engine.Run(self.p, self.training)
         outs = engine.EncoderFn.apply(self, run, src.contiguous(), ops.to_mask_u8(src_mask), econds,
-                                      self.get_attn, *self.trunk_params())
+                                      self.get_attn, _keys, *self.trunk_params())
         if self.get_attn:
             return outs[0], list(outs[1:])
         return outs, None
@@ -76,7 +76,7 @@ class Decoder(nn.Module, _TrunkParams):
         if use_cond2lat and nconds > 0:
             self.embed_cond2lat = nn.Linear(nconds, d_model * nconds)
 
-    def forward(self, trg, z, src_mask, trg_mask, dconds, loss_rows=None, _compact_out=False):
+    def forward(self, trg, z, src_mask, trg_mask, dconds, loss_rows=None, _compact_out=False, _plan=None):
         """loss_rows (bool / uint8 [B, T], optional -- an extension of this build): the rows whose output reaches the
         loss; the others are not computed and come back as zeros (engine.decoder_trunk_fwd)."""
         run = engine.Run(self.p, self.training)
@@ -84,7 +84,7 @@ class Decoder(nn.Module, _TrunkParams):
             loss_rows = loss_rows.to(torch.uint8).contiguous()
         self._gct_live_out = None
         outs = engine.DecoderFn.apply(self, run, trg.contiguous(), z, ops.to_mask_u8(src_mask),
-                                      ops.to_mask_u8(trg_mask), dconds, self.get_attn, loss_rows,
+                                      ops.to_mask_u8(trg_mask), dconds, self.get_attn, loss_rows, _plan,
                                       *self.trunk_params())
         if self._gct_live_out is not None and not _compact_out:
             # the trunk ran on the loss rows only and returned them compact [Mc, d]: a caller of the decoder alone gets
@@ -96,6 +96,25 @@ class Decoder(nn.Module, _TrunkParams):
             n = self.N
             return outs[0], list(outs[1:1 + n]), list(outs[1 + n:1 + 2 * n])
         return outs
+
+
+def _row_plan(model, src_mask, trg_mask, loss_rows, trg):
+    """engine.RowPlan of a training-style forward: the row maps of both trunks, read back in ONE synchronisation at the
+    start of the step (see engine.RowPlan).  Works on the masks exactly as the caller passed them (Model/modules.py)."""
+    if model.get_attn or src_mask is None or not src_mask.is_cuda:
+        return engine.RowPlan()
+    dec = model.decoder
+    sm = ops.to_mask_u8(src_mask)
+    B, T = trg.shape
+    if sm.dim() != 3 or sm.shape[0] != B or sm.shape[1] != 1:          # not the reference's [B, 1, L] key-padding mask
+        return engine.RowPlan()
+    Le = sm.shape[2]
+    c2d = dec.use_cond2dec and dec.nconds > 0
+    nc_lat = dec.nconds if (not c2d and dec.use_cond2lat and dec.nconds > 0) else 0
+    lr = None if loss_rows is None else loss_rows.to(torch.uint8).contiguous()
+    tm = None if trg_mask is None else ops.to_mask_u8(trg_mask)
+    return engine.RowPlan.build(sm.view(B, Le), tm, lr, B, Le, T if not c2d else T + dec.nconds, nc_lat,
+                                len(model.encoder.layers), len(dec.layers))
 
 
 class Linear(nn.Linear):
@@ -144,11 +163,12 @@ class Vaetf(FlatModelMixin, nn.Module):
         """Reference signature (Model/vaetf.py:154) plus one keyword-only extension: loss_rows (bool [B, T]) names the
         decoder rows whose logits reach the loss -- the trainer passes `ys != pad` (Model/forward_propagation1.py); the
         other rows are then not computed at all and their logits come back as zeros, NOT as the reference's values.  Default (None): every row, as the reference."""
-        x, enc_attn = self.encoder.trunk(src, src_mask, econds)
-        z, mu, log_var = self.sampler(x)
         if self.get_attn or (self.use_cond2dec and self.nconds > 0):
             loss_rows = None
-        d = self.decoder(trg, z, src_mask, trg_mask, dconds, loss_rows, _compact_out=True)
+        plan = _row_plan(self, src_mask, trg_mask, loss_rows, trg)
+        x, enc_attn = self.encoder.trunk(src, src_mask, econds, _keys=plan.enc_keys)
+        z, mu, log_var = self.sampler(x)
+        d = self.decoder(trg, z, src_mask, trg_mask, dconds, loss_rows, _compact_out=True, _plan=plan)
         if self.get_attn:
             d, dec_attn_1, dec_attn_2 = d
         output = self.out(d)

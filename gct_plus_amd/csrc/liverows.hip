@@ -178,6 +178,24 @@ __global__ __launch_bounds__(256) void scatter_quads_kernel(const float* __restr
   }
 }
 
+// dst[4 * quad_list[i / 4] + i % 4][:] += src[i][:] (compact quads are disjoint: no atomics)
+__global__ __launch_bounds__(256) void scatter_add_quads_kernel(const float* __restrict__ src, int64_t ld,
+                                                                const int32_t* __restrict__ quad_list, int64_t nrows,
+                                                                int c4, float* __restrict__ dst, int64_t ldd, int64_t M) {
+  const int64_t total = nrows * c4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / c4;
+    const int c = (int)(i - row * c4);
+    const int q = quad_list[row >> 2];
+    const int64_t r = (int64_t)q * 4 + (row & 3);
+    if (q >= 0 && r < M) {
+      float4* d = reinterpret_cast<float4*>(dst + r * ldd + c * 4);
+      const float4 a = *d, b = *reinterpret_cast<const float4*>(src + row * ld + c * 4);
+      *d = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+  }
+}
+
 // the same two maps for any column count / alignment (the vocabulary head's 28-31 logits per row): one element per thread
 __global__ __launch_bounds__(256) void gather_quads_scalar_kernel(const float* __restrict__ src, int64_t ld, int64_t M,
                                                                   const int32_t* __restrict__ quad_list, int64_t nrows,
@@ -405,5 +423,20 @@ extern "C" int gct_scatter_quads(const float* src, int64_t ld, const int32_t* qu
   hipLaunchKernelGGL(scatter_quads_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, src, ld, quad_list,
                      nrows, cols / 4, dst, ldd, M);
   GCT_LAUNCH_CHECK("scatter_quads");
+  return GCT_OK;
+}
+
+extern "C" int gct_scatter_add_quads(const float* src, int64_t ld, const int32_t* quad_list, int64_t nrows, int cols,
+                                     float* dst, int64_t ldd, int64_t M, void* stream) {
+  GCT_CHECK_ARG(src && quad_list && dst && nrows >= 0 && nrows % 4 == 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 &&
+                    ldd % 4 == 0 && gct_aligned16(src) && gct_aligned16(dst),
+                "scatter_add_quads: bad args");
+  if (nrows == 0) return GCT_OK;
+  const int64_t work = nrows * (cols / 4);
+  int64_t grid = (work + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(scatter_add_quads_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, src, ld, quad_list,
+                     nrows, cols / 4, dst, ldd, M);
+  GCT_LAUNCH_CHECK("scatter_add_quads");
   return GCT_OK;
 }

@@ -34,6 +34,8 @@ COMPACT_MAX_FRACTION = 0.85
 COMPACT_KV = os.environ.get("GCT_COMPACT_KV", "1") != "0"
 # Decoder FORWARD over the rows that reach the loss only (decoder_trunk_fwd(loss_rows=...)): GCT_COMPACT_FWD=0 disables.
 COMPACT_FWD = os.environ.get("GCT_COMPACT_FWD", "1") != "0"
+# K | V projections of the ENCODER self-attention over the visible rows only (mha_fwd): GCT_COMPACT_ENC_KV=0 disables.
+COMPACT_ENC_KV = os.environ.get("GCT_COMPACT_ENC_KV", "1") != "0"
 
 
 # Data parallelism (dp.FlatDataParallel) sets this while a backward pass is running: called as
@@ -47,6 +49,62 @@ def _grads_done(module, G: "GradSink"):
     if GRAD_NOTIFY is not None:
         ps = list(module.parameters())
         GRAD_NOTIFY(ps, [G.out.get(p) for p in ps])
+
+
+class RowPlan:
+    """The row maps of one training step, built and read back TOGETHER at the start of model.forward (one device->host
+    synchronisation per step, taken while the GPU is still finishing the previous step -- the host then runs ahead for the
+    whole step instead of stalling at the decoder's entry):
+      enc_keys  ops.KeyRows of the encoder's key-padding mask  -> K | V of the encoder self-attention on visible rows
+      dec_keys  ops.KeyRows of the decoder's memory mask       -> cross-attention K | V on visible rows
+      live      ops.LiveRows of the rows that reach the loss   -> decoder forward / backward on those rows
+    Each is None when its shortcut does not apply (switch off, mask not a prefix, too little to gain)."""
+
+    def __init__(self, enc_keys=None, dec_keys=None, live=None):
+        self.enc_keys, self.dec_keys, self.live = enc_keys, dec_keys, live
+
+    @staticmethod
+    def usable_keys(kr, rows):
+        if kr is None:
+            return None
+        h = kr.host()
+        ok = h["nonprefix"] == 0 and h["empty"] == 0 and 0 < h["padded"] <= COMPACT_MAX_FRACTION * rows
+        return kr if ok else None
+
+    @staticmethod
+    def usable_live(lr, rows):
+        if lr is None:
+            return None
+        h = lr.host()
+        ok = h["violations"] == 0 and h["nonprefix"] == 0 and 0 < h["padded"] <= COMPACT_MAX_FRACTION * rows
+        return lr if ok else None
+
+    @classmethod
+    def build(cls, src_mask_u8, trg_mask_u8, loss_rows, B, Le, T, nc_lat, n_layers_enc, n_layers_dec):
+        """src_mask_u8 [B, Le] (encoder keys, condition rows included); the decoder's memory mask is the same with nc_lat
+        visible condition rows in front (use_cond2lat); loss_rows uint8 [B, T] or None."""
+        if torch.cuda.is_current_stream_capturing() or src_mask_u8 is None or src_mask_u8.numel() != B * Le:
+            return cls()
+        sm = src_mask_u8.view(B, Le)
+        ek = ops.KeyRows(sm, B, Le) if (COMPACT_ENC_KV and n_layers_enc > 0) else None
+        dk = None
+        if COMPACT_KV and n_layers_dec > 0:
+            if nc_lat > 0:
+                ones = torch.ones(B, nc_lat, dtype=torch.uint8, device=sm.device)
+                dk = ops.KeyRows(torch.cat([ones, sm], dim=1).contiguous(), B, Le + nc_lat)
+            elif ek is not None:
+                dk = ek                                  # the same mask: one map serves both trunks
+            else:
+                dk = ops.KeyRows(sm, B, Le)
+        lr = None
+        if (COMPACT_FWD and loss_rows is not None and trg_mask_u8 is not None and T <= 96 and Le + nc_lat <= 96
+                and n_layers_dec > 0):
+            lr = ops.LiveRows.from_rows(loss_rows.reshape(B, T), B, T, trg_mask_u8)
+        ops.read_back(ek, dk, lr)                        # ONE synchronisation for all three
+        plan = cls(cls.usable_keys(ek, B * Le), cls.usable_keys(dk, B * (Le + nc_lat)), cls.usable_live(lr, B * T))
+        if plan.live is not None:
+            plan.live.fwd = True
+        return plan
 
 
 def next_seed() -> int:
@@ -121,7 +179,14 @@ def mha_fwd(run: Run, m, xq, xkv, B, Lq, Lk, mask_u8, resid, want_probs=False, k
     dk = d // H
     self_attn = xkv is xq
     Mq = xq.shape[0]
-    if self_attn:
+    # Self-attention under a key-padding mask (the encoder): the K / V projections of masked rows are never read and
+    # their dK / dV are exactly zero, so K | V run on the VISIBLE rows only (keys: ops.KeyRows of the mask; 56 % fewer
+    # rows at MOSES-like lengths) while Q -- every row's output feeds the KL term -- runs on all of them.  From here on
+    # it is the cross-attention path with xkv = the gathered visible rows of xq.
+    self_split = self_attn and keys is not None and live is None and not want_probs
+    if self_split:
+        xkv = keys.gather(xq)
+    if self_attn and not self_split:
         qkv = _empty(Mq, 3 * d, xq)
         ops.linear_fwd(xq, [m.q_linear.weight, m.k_linear.weight, m.v_linear.weight],
                        [m.q_linear.bias, m.k_linear.bias, m.v_linear.bias],
@@ -149,7 +214,7 @@ def mha_fwd(run: Run, m, xq, xkv, B, Lq, Lk, mask_u8, resid, want_probs=False, k
     else:
         ops.linear_fwd(o, [m.out.weight], [m.out.bias], [y], d)
     saved = (xq, xkv, qb, kvb, o, lse, mask_u8, B, Lq, Lk, site_p, site_o, resid is not None,
-             None if (self_attn and live is not None) else keys)
+             None if (self_attn and live is not None) else keys, self_split)
     return y, saved, probs
 
 
@@ -161,7 +226,7 @@ def mha_bwd(run: Run, m, saved, dy, G: GradSink, dxq_out, depi_q, dxkv_out=None,
     d(xkv) into dxkv_out (epilogue depi_kv).  The identity path to `resid` is the caller's.
     live (ops.LiveRows): the QUERY-side rows (dy, dxq_out) are quad-compacted; saved forward tensors are
     gathered on the way in, key/value-side gradients of cross-attention stay in the encoder's row space."""
-    xq, xkv, qb, kvb, o, lse, mask_u8, B, Lq, Lk, site_p, site_o, fused, keys = saved
+    xq, xkv, qb, kvb, o, lse, mask_u8, B, Lq, Lk, site_p, site_o, fused, keys, self_split = saved
     d, H = m.d_model, m.h
     dk = d // H
     Mq, Mk = B * Lq, xkv.shape[0]
@@ -209,7 +274,11 @@ def mha_bwd(run: Run, m, saved, dy, G: GradSink, dxq_out, depi_q, dxkv_out=None,
                          [G(m.k_linear.weight), G(m.v_linear.weight)],
                          [G(m.k_linear.bias), G(m.v_linear.bias)])
         ops.linear_dgrad([dq], d, Mq, [m.q_linear.weight], dxq_out, depi=depi_q)
-        if dxkv_out is not None:
+        if self_split:       # K | V came from the visible rows of xq itself: their input gradient goes back into d(xq)
+            dxk = keys.empty(d)
+            ops.linear_dgrad([dkv, dkv[:, d:]], 2 * d, Mk, [m.k_linear.weight, m.v_linear.weight], dxk)
+            keys.scatter_add(dxk, dxq_out)
+        elif dxkv_out is not None:
             ops.linear_dgrad([dkv, dkv[:, d:]], 2 * d, Mk, [m.k_linear.weight, m.v_linear.weight],
                              dxkv_out, depi=depi_kv)
 
@@ -256,9 +325,9 @@ def ffn_bwd(run: Run, ff, saved, dy, G: GradSink, dx_out, depi, live=None, gdrop
 
 
 # ---------------------------------------------------------------------------------- layers
-def enc_layer_fwd(run: Run, layer, x_in, B, L, mask_u8, want_probs=False):
+def enc_layer_fwd(run: Run, layer, x_in, B, L, mask_u8, want_probs=False, keys=None):
     n1, m1, r1 = ops.norm_fwd(x_in, layer.norm_1.alpha, layer.norm_1.bias, layer.norm_1.eps)
-    a, sv_a, probs = mha_fwd(run, layer.attn, n1, n1, B, L, L, mask_u8, n1, want_probs)
+    a, sv_a, probs = mha_fwd(run, layer.attn, n1, n1, B, L, L, mask_u8, n1, want_probs, keys=keys)
     n2, m2, r2 = ops.norm_fwd(a, layer.norm_2.alpha, layer.norm_2.bias, layer.norm_2.eps)
     out, sv_f = ffn_fwd(run, layer.ff, n2, n2)
     return out, (x_in, m1, r1, sv_a, a, m2, r2, sv_f), probs
@@ -335,8 +404,10 @@ def _pe2d(pe_mod, L):
     return pe[0]
 
 
-def encoder_trunk_fwd(enc, run: Run, src, mask_u8, econds, want_probs=False):
-    """Model/vaetf.py:32-54 (up to the final Norm).  Returns x [B, n_c+S, d] and saved state."""
+def encoder_trunk_fwd(enc, run: Run, src, mask_u8, econds, want_probs=False, keys=None):
+    """Model/vaetf.py:32-54 (up to the final Norm).  Returns x [B, n_c+S, d] and saved state.
+    keys (ops.KeyRows of the key-padding mask, usable(): checked by the caller): the K | V projections of every layer
+    run on the visible rows only (mha_fwd)."""
     B, S = src.shape
     d, nc = enc.d_model, enc.nconds
     cond = None
@@ -352,7 +423,7 @@ def encoder_trunk_fwd(enc, run: Run, src, mask_u8, econds, want_probs=False):
                          math.sqrt(d), run.p, run.seed, site_pe)
     lsv, probs = [], []
     for layer in enc.layers:
-        x, sv, pr = enc_layer_fwd(run, layer, x, B, L, mask_u8, want_probs)
+        x, sv, pr = enc_layer_fwd(run, layer, x, B, L, mask_u8, want_probs, keys=keys)
         lsv.append(sv)
         probs.append(pr)
     y, mean, rstd = ops.norm_fwd(x, enc.norm.alpha, enc.norm.bias, enc.norm.eps)
@@ -380,7 +451,8 @@ def encoder_trunk_bwd(enc, run: Run, saved, dy, G: GradSink):
                              G(enc.embed_cond2enc.bias))
 
 
-def decoder_trunk_fwd(dec, run: Run, trg, z, src_mask_u8, trg_mask_u8, dconds, want_probs=False, loss_rows=None):
+def decoder_trunk_fwd(dec, run: Run, trg, z, src_mask_u8, trg_mask_u8, dconds, want_probs=False, loss_rows=None,
+                      plan=None):
     """Model/vaetf.py:79-114.  z [B, L_e, latent].
     loss_rows (uint8 [B, T], optional): the decoder rows whose output reaches the loss (the reference's cross-entropy
     ignores the rows of padded targets, Train/trainer1.py:21-22: 56 % of the rows at MOSES-like lengths).  A row outside
@@ -423,34 +495,36 @@ def decoder_trunk_fwd(dec, run: Run, trg, z, src_mask_u8, trg_mask_u8, dconds, w
             src_mask_u8 = torch.cat([ones, src_mask_u8.view(B, Le)], dim=1).contiguous()
     lsv, p1s, p2s = [], [], []
     capturing = torch.cuda.is_current_stream_capturing()
-    # the live rows of the forward (loss_rows): one device pass builds the maps and checks the no-dead-key condition;
-    # its read-back is shared with the key-row map below (the kernels of both are queued before either is read)
-    live = None
-    lr = None
-    if (COMPACT_FWD and loss_rows is not None and not c2d and not want_probs and T <= 96 and Lk <= 96
-            and len(dec.layers) > 0 and not capturing and trg_mask_u8 is not None):
-        tm_u8 = trg_mask_u8.u8 if isinstance(trg_mask_u8, ops.MaskBits) else trg_mask_u8
-        lr = ops.LiveRows.from_rows(loss_rows.reshape(B, T), B, T, tm_u8)
-    # Padded rows of the encoder memory are masked keys of every cross-attention: their K / V projections are never
-    # used and their dK / dV are zero.  When src_mask is a key-padding mask whose visible keys form a prefix of
-    # every sample (device check, one 32-byte read-back), the six K|V GEMMs, their weight gradients and the
-    # gradient w.r.t. the memory run on the visible rows only (quad-compacted, ops.KeyRows).
-    keys = None
-    kr = None
-    if (COMPACT_KV and src_mask_u8 is not None and src_mask_u8.numel() == B * Lk and len(dec.layers) > 0
-            and not capturing):
-        kr = ops.KeyRows(src_mask_u8.view(B, Lk), B, Lk)
-    if lr is not None:
-        h = lr.host()
-        if h["violations"] == 0 and h["nonprefix"] == 0 and 0 < h["padded"] <= COMPACT_MAX_FRACTION * B * T:
-            live = lr
+    # Row maps.  `plan` (engine.RowPlan, built and read back at the start of model.forward): use what it validated.
+    # Without one (the decoder called on its own, decode prefill) they are built here -- their kernels are queued before
+    # either is read, so both come back in one synchronisation:
+    #   live  the rows that reach the loss (loss_rows): forward and backward of the trunk run on them only;
+    #   keys  the visible rows of the encoder memory: padded rows are masked keys of every cross-attention, their K / V
+    #         projections are never used and their dK / dV are zero, so the six K|V GEMMs, their weight gradients and
+    #         the gradient w.r.t. the memory run on the visible rows only (quad-compacted, ops.KeyRows).
+    live, keys = None, None
+    fwd_ok = (not c2d and not want_probs and T <= 96 and Lk <= 96 and len(dec.layers) > 0 and not capturing
+              and trg_mask_u8 is not None)
+    if plan is not None:
+        live = plan.live if fwd_ok else None
+        keys = plan.dec_keys if (src_mask_u8 is not None and src_mask_u8.numel() == B * Lk) else None
+    else:
+        lr = kr = None
+        if COMPACT_FWD and loss_rows is not None and fwd_ok:
+            tm_u8 = trg_mask_u8.u8 if isinstance(trg_mask_u8, ops.MaskBits) else trg_mask_u8
+            lr = ops.LiveRows.from_rows(loss_rows.reshape(B, T), B, T, tm_u8)
+        if (COMPACT_KV and src_mask_u8 is not None and src_mask_u8.numel() == B * Lk and len(dec.layers) > 0
+                and not capturing):
+            kr = ops.KeyRows(src_mask_u8.view(B, Lk), B, Lk)
+        ops.read_back(lr, kr)
+        live = RowPlan.usable_live(lr, B * T)
+        keys = RowPlan.usable_keys(kr, B * Lk)
+        if live is not None:
             live.fwd = True
-            x = live.gather(x)
-    if kr is not None:
-        h = kr.host()
-        if h["nonprefix"] == 0 and h["empty"] == 0 and 0 < h["padded"] <= COMPACT_MAX_FRACTION * B * Lk:
-            keys = kr
-            e = keys.gather(e)
+    if live is not None:
+        x = live.gather(x)
+    if keys is not None:
+        e = keys.gather(e)
     src_m = ops.pack_mask(src_mask_u8, B, T, Lk)
     trg_m = ops.pack_mask(trg_mask_u8, B, T, T)
     for layer in dec.layers:
@@ -553,8 +627,8 @@ def _f32c(t):
 
 class EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, enc, run, src, mask_u8, econds, want_probs, *params):
-        y, saved, probs = encoder_trunk_fwd(enc, run, src, mask_u8, econds, want_probs)
+    def forward(ctx, enc, run, src, mask_u8, econds, want_probs, keys, *params):
+        y, saved, probs = encoder_trunk_fwd(enc, run, src, mask_u8, econds, want_probs, keys=keys)
         ctx.enc, ctx.run, ctx.saved, ctx.params = enc, run, saved, params
         if want_probs:
             for p in probs:
@@ -567,14 +641,14 @@ class EncoderFn(torch.autograd.Function):
         G = GradSink()
         encoder_trunk_bwd(ctx.enc, ctx.run, ctx.saved, _f32c(dy), G)
         ctx.saved = None
-        return (None,) * 6 + G.collect(ctx.params)
+        return (None,) * 7 + G.collect(ctx.params)
 
 
 class DecoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, dec, run, trg, z, src_mask_u8, trg_mask_u8, dconds, want_probs, loss_rows, *params):
+    def forward(ctx, dec, run, trg, z, src_mask_u8, trg_mask_u8, dconds, want_probs, loss_rows, plan, *params):
         y, saved, p1, p2 = decoder_trunk_fwd(dec, run, trg, _f32c(z), src_mask_u8, trg_mask_u8,
-                                             dconds, want_probs, loss_rows=loss_rows)
+                                             dconds, want_probs, loss_rows=loss_rows, plan=plan)
         ctx.dec, ctx.run, ctx.saved, ctx.params = dec, run, saved, params
         dec._gct_live_out = saved[-1]          # not None: y holds the COMPACT live rows [Mc, d] (Decoder.forward hands
                                                # the map to its caller, who scatters what it needs: ScatterRowsFn)
@@ -590,7 +664,7 @@ class DecoderFn(torch.autograd.Function):
         G = GradSink()
         dz = decoder_trunk_bwd(ctx.dec, ctx.run, ctx.saved, _f32c(dy), G, ctx.need_dz)
         ctx.saved = None
-        return (None, None, None, dz, None, None, None, None, None) + G.collect(ctx.params)
+        return (None, None, None, dz, None, None, None, None, None, None) + G.collect(ctx.params)
 
 
 class ScatterRowsFn(torch.autograd.Function):

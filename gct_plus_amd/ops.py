@@ -349,6 +349,10 @@ def nonzero_row_tiles(x2d: torch.Tensor):
 
 
 _SKIPPED = {}
+_SKIPPED_MSG = ("{} decoder rows that an earlier forward skipped (loss_rows: rows that do not reach the loss) received a "
+                "non-zero gradient in its backward pass: that gradient was ignored.  Call the model without loss_rows "
+                "(forward_propagation(..., skip_ignored=False)) for losses other than the reference's ignore_index "
+                "cross-entropy.")
 
 
 def skipped_row_gradients():
@@ -404,19 +408,21 @@ class LiveRows:
         _chk(rows_u8, "live_rows.rows", torch.uint8)
         return cls(rows_u8.reshape(B * T, 1).to(torch.float32), B, T, mask_u8)
 
+    def _fill_host(self, v):
+        self._host = dict(n_live=v[0], violations=v[1], nonprefix=v[2], tiles=v[3], padded=v[4], quads=v[5], empty=v[6])
+        self.Mc = v[4]
+
     def host(self):
         if self._host is None:
-            v = torch.cat([self.info, skipped_row_gradients()]).tolist()          # ONE read-back
-            self._host = dict(n_live=v[0], violations=v[1], nonprefix=v[2], tiles=v[3], padded=v[4], quads=v[5])
-            self.Mc = v[4]
-            if v[8] != 0:
-                skipped_row_gradients().zero_()
-                raise _lib.GctError(
-                    f"{v[8]} decoder rows that an earlier forward skipped (loss_rows: rows that do not reach the loss) "
-                    "received a non-zero gradient in its backward pass: that gradient was ignored.  Call the model "
-                    "without loss_rows (forward_propagation(..., skip_ignored=False)) for losses other than the "
-                    "reference's ignore_index cross-entropy.")
+            read_back(self)                                 # ONE read-back (also of the skipped-row gradient counter)
         return self._host
+
+    def scatter_add(self, src2d, dst2d):
+        """dst2d [M, cols] rows += the compact rows src2d [Mc, cols]."""
+        cols = src2d.shape[1]
+        check(_L().gct_scatter_add_quads(_p(src2d), src2d.stride(0), _p(self.quad_list), self.Mc, cols, _p(dst2d),
+                                         dst2d.stride(0), self.M, _st()), "gct_scatter_add_quads")
+        return dst2d
 
     def check_grad(self, g2d):
         """The backward of a forward that ran on these rows only: count the gradient rows outside them that are not
@@ -445,6 +451,19 @@ class LiveRows:
         return dst
 
 
+def read_back(*objs):
+    """host() of several LiveRows / KeyRows with ONE device->host copy (one synchronisation instead of one each)."""
+    objs = [o for o in objs if o is not None and o._host is None]
+    if not objs:
+        return
+    v = torch.cat([o.info for o in objs] + [skipped_row_gradients()]).tolist()
+    for i, o in enumerate(objs):
+        o._fill_host(v[8 * i:8 * i + 8])
+    if v[-1] != 0:
+        skipped_row_gradients().zero_()
+        raise _lib.GctError(_SKIPPED_MSG.format(v[-1]))
+
+
 class KeyRows(LiveRows):
     """The compaction map of the KEY side of cross-attention, from a key-padding mask [B, Lk] (gct_key_rows): the
     padded rows of the encoder memory are masked keys, so their K / V projections (and dK / dV) need not exist.
@@ -466,12 +485,7 @@ class KeyRows(LiveRows):
         self._host = None
         self.Mc = None
 
-    def host(self):
-        if self._host is None:
-            v = self.info.tolist()
-            self._host = dict(n_live=v[0], nonprefix=v[2], padded=v[4], quads=v[5], empty=v[6])
-            self.Mc = v[4]
-        return self._host
+    # (host(): LiveRows' -- the same 8-word info record, read together with whatever else is pending)
 
 
 def linear_wgrad(dys: Sequence[torch.Tensor], lddy: int, x2d, dws: Sequence[torch.Tensor],

@@ -226,6 +226,9 @@ int gct_gather_quads(const float* src, int64_t ld, int64_t M, const int32_t* qua
                      float* dst, int64_t ldd, void* stream);
 int gct_scatter_quads(const float* src, int64_t ld, const int32_t* quad_list, int64_t nrows, int cols, float* dst,
                       int64_t ldd, int64_t M, void* stream);
+/* dst rows += the compact rows (gradient of rows that were gathered: the encoder's K | V over its visible rows) */
+int gct_scatter_add_quads(const float* src, int64_t ld, const int32_t* quad_list, int64_t nrows, int cols, float* dst,
+                          int64_t ldd, int64_t M, void* stream);
 int gct_linear_wgrad_kt(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
                         int64_t M, int nseg, int nper, const float* x, int64_t ldx, int K,
                         float* dw0, float* dw1, float* dw2, int64_t lddw,

@@ -593,6 +593,7 @@ def test_compacted_decoder_backward_matches_dense(mtype, kw, B, S, p, monkeypatc
     for mode in (True, False):
         monkeypatch.setattr(engine, "COMPACT_BWD", mode)
         monkeypatch.setattr(engine, "COMPACT_KV", mode)          # cross-attention over the visible memory rows only
+        monkeypatch.setattr(engine, "COMPACT_ENC_KV", mode)      # encoder self-attention K | V over the visible rows only
         seen = []
         real = engine.ops.LiveRows.gather
         monkeypatch.setattr(engine.ops.LiveRows, "gather", lambda self, *a, **k: (seen.append(1), real(self, *a, **k))[1])
@@ -639,7 +640,7 @@ def test_decoder_forward_over_loss_rows_matches_dense(mtype, kw, B, S, p, monkey
     nc = synthetic.n_conds(mtype)
     eps = torch.randn(B, S + nc, kw.get("latent_dim", TINY["latent_dim"]), generator=torch.Generator().manual_seed(2))
     res, took = {}, {}
-    for name in ("COMPACT_FWD", "COMPACT_BWD", "COMPACT_KV"):
+    for name in ("COMPACT_FWD", "COMPACT_BWD", "COMPACT_KV", "COMPACT_ENC_KV"):
         monkeypatch.setattr(engine, name, True)
     for skip in (True, False):
         seen = []

@@ -15,7 +15,7 @@ DIMS = dict(N=6, d_model=512, dff=2048, h=8, latent_dim=128)
 
 
 def run(mtype, B, compact, S=80):
-    engine.COMPACT_BWD = engine.COMPACT_KV = engine.COMPACT_FWD = compact
+    engine.COMPACT_BWD = engine.COMPACT_KV = engine.COMPACT_FWD = engine.COMPACT_ENC_KV = compact
     engine._SEED.update(base=None, ctr=0)          # same dropout / eps streams in both runs
     vs, vt = synthetic.vocab_sizes(mtype)
     nc = synthetic.n_conds(mtype)
@@ -43,11 +43,11 @@ def run(mtype, B, compact, S=80):
 
 def compare(mtype, B, S=80):
     """max relative difference of the three per-sample losses, shortcuts on vs off"""
-    keep = (engine.COMPACT_BWD, engine.COMPACT_KV, engine.COMPACT_FWD)
+    keep = (engine.COMPACT_BWD, engine.COMPACT_KV, engine.COMPACT_FWD, engine.COMPACT_ENC_KV)
     try:
         on, off = run(mtype, B, True, S), run(mtype, B, False, S)
     finally:
-        engine.COMPACT_BWD, engine.COMPACT_KV, engine.COMPACT_FWD = keep     # module state: leave it as it was found
+        engine.COMPACT_BWD, engine.COMPACT_KV, engine.COMPACT_FWD, engine.COMPACT_ENC_KV = keep    # leave the module as found
     assert all(x == x for x in on + off), (mtype, B, on, off)
     return max(abs(x - y) / max(abs(y), 1e-9) for x, y in zip(on, off)), on, off
 
