@@ -48,6 +48,7 @@ SIGNATURES = {
     "gct_live_rows": (I32, [P, I64, I32, I32, I32, P, I64, I64, P, P, P, P, P, P, P, P, P, P]),
     "gct_gather_quads": (I32, [P, I64, I64, P, I64, I32, P, I64, P]),
     "gct_scatter_quads": (I32, [P, I64, P, I64, I32, P, I64, I64, P]),
+    "gct_zero_gap_rows": (I32, [P, I64, I32, P, P, I32, I64, P]),
     "gct_scatter_add_quads": (I32, [P, I64, P, I64, I32, P, I64, I64, P]),
     "gct_linear_wgrad_kt": (I32, [P, P, P, I64, I64, I32, I32, P, I64, I32, P, P, P, I64, P, P, P,
                                   P, P, P, P]),

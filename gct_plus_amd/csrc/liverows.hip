@@ -196,6 +196,23 @@ __global__ __launch_bounds__(256) void scatter_add_quads_kernel(const float* __r
   }
 }
 
+// zero the rows of a compact buffer that belong to no sample's live prefix: [cstart[b] + n_b[b], cstart[b + 1]) for every
+// sample (the padded rows that travel with a live quad) and everything behind the last sample up to `nrows` (the -1
+// padding quads).  A handful of rows per sample instead of a fill of the whole buffer.
+__global__ __launch_bounds__(256) void zero_gap_rows_kernel(float* __restrict__ buf, int64_t ld, int c4,
+                                                            const int32_t* __restrict__ cstart,
+                                                            const int32_t* __restrict__ n_b, int B, int64_t nrows) {
+  const int b = blockIdx.x;
+  const int64_t r0 = (int64_t)cstart[b] + n_b[b];
+  const int64_t r1 = b + 1 < B ? (int64_t)cstart[b + 1] : nrows;
+  const int64_t total = (r1 - r0) * c4;
+  for (int64_t i = threadIdx.x; i < total; i += 256) {
+    const int64_t row = r0 + i / c4;
+    const int c = (int)(i % c4);
+    *reinterpret_cast<float4*>(buf + row * ld + c * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 // the same two maps for any column count / alignment (the vocabulary head's 28-31 logits per row): one element per thread
 __global__ __launch_bounds__(256) void gather_quads_scalar_kernel(const float* __restrict__ src, int64_t ld, int64_t M,
                                                                   const int32_t* __restrict__ quad_list, int64_t nrows,
@@ -438,5 +455,16 @@ extern "C" int gct_scatter_add_quads(const float* src, int64_t ld, const int32_t
   hipLaunchKernelGGL(scatter_add_quads_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, src, ld, quad_list,
                      nrows, cols / 4, dst, ldd, M);
   GCT_LAUNCH_CHECK("scatter_add_quads");
+  return GCT_OK;
+}
+
+extern "C" int gct_zero_gap_rows(float* buf, int64_t ld, int cols, const int32_t* cstart, const int32_t* n_b, int B,
+                                 int64_t nrows, void* stream) {
+  GCT_CHECK_ARG(buf && cstart && n_b && B >= 0 && nrows >= 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 && gct_aligned16(buf),
+                "zero_gap_rows: bad args");
+  if (B == 0) return GCT_OK;
+  hipLaunchKernelGGL(zero_gap_rows_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, buf, ld, cols / 4, cstart,
+                     n_b, B, nrows);
+  GCT_LAUNCH_CHECK("zero_gap_rows");
   return GCT_OK;
 }

@@ -235,7 +235,7 @@ def mha_bwd(run: Run, m, saved, dy, G: GradSink, dxq_out, depi_q, dxkv_out=None,
     if live is not None:
         Mq, kt = live.Mc, None
         # rows of a live quad that belong to no sample's live prefix are never written by the attention kernel
-        new = lambda cols: torch.zeros(live.Mc + live.SLACK, cols, dtype=torch.float32, device=dy.device)[:live.Mc]   # noqa: E731
+        new = live.empty_zero_gaps
         # (a forward that ran on the compact rows saved compact activations: nothing to gather)
         o_in, xq_in = (o, xq) if live.fwd else (live.gather(o), live.gather(xq))
     else:
@@ -266,7 +266,7 @@ def mha_bwd(run: Run, m, saved, dy, G: GradSink, dxq_out, depi_q, dxkv_out=None,
         if keys is None:
             dkv = _empty(Mk, 2 * d, dy)
         else:      # compacted keys: the rows that pad a quad belong to no sample and are never written
-            dkv = torch.zeros(keys.Mc + keys.SLACK, 2 * d, dtype=torch.float32, device=dy.device)[:keys.Mc]
+            dkv = keys.empty_zero_gaps(2 * d)
         ops.attn_bwd(qb, kvb, kvb[:, d:], d, 2 * d, 2 * d, mask_u8, o, do, lse, dq, dkv, dkv[:, d:],
                      d, 2 * d, 2 * d, B, H, Lq, Lk, dk, run.p, run.seed, site_p, live=live, keys=keys)
         ops.linear_wgrad([dq], d, xq_in, [G(m.q_linear.weight)], [G(m.q_linear.bias)], kt=kt)   # query rows

@@ -434,6 +434,16 @@ class LiveRows:
         """A compact [Mc, cols] activation (with SLACK rows of allocation behind it)."""
         return torch.empty(self.Mc + self.SLACK, cols, dtype=torch.float32, device=self.dev)[:self.Mc]
 
+    def empty_zero_gaps(self, cols):
+        """A compact [Mc, cols] buffer for a kernel that writes the rows cstart[b] .. + n_b[b] of every sample only
+        (attention over compact rows): uninitialised, except that the rows in between -- padded rows that travel with a
+        live quad, the padding quads at the end -- are zero, so that the GEMMs that consume all Mc rows see finite
+        values there (a few rows per sample instead of a fill of the whole buffer)."""
+        t = self.empty(cols)
+        check(_L().gct_zero_gap_rows(_p(t), t.stride(0), cols, _p(self.cstart), _p(self.n_b), self.B, self.Mc, _st()),
+              "gct_zero_gap_rows")
+        return t
+
     def gather(self, src2d, out=None):
         """src2d [M, cols] (row stride >= cols) -> compact [Mc, cols]; padding rows are zero."""
         cols = src2d.shape[1]
@@ -590,7 +600,7 @@ def attn_fwd(q, k, v, ld_q, ld_k, ld_v, mask, B, H, Lq, Lk, dk, p, seed, site, o
     if out is not None:
         o = out
     elif live is not None:     # rows of a live quad outside every sample's live prefix are not written: keep them finite
-        o = torch.zeros(live.Mc + live.SLACK, H * dk, dtype=torch.float32, device=dev)[:live.Mc]
+        o = live.empty_zero_gaps(H * dk)
     else:
         o = torch.empty(B * Lq, H * dk, dtype=torch.float32, device=dev)
     lse = torch.empty(B * H * Lq, dtype=torch.float32, device=dev)

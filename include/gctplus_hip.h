@@ -226,6 +226,11 @@ int gct_gather_quads(const float* src, int64_t ld, int64_t M, const int32_t* qua
                      float* dst, int64_t ldd, void* stream);
 int gct_scatter_quads(const float* src, int64_t ld, const int32_t* quad_list, int64_t nrows, int cols, float* dst,
                       int64_t ldd, int64_t M, void* stream);
+/* Zero the rows of a compact [nrows][cols] buffer that belong to no sample: [cstart[b] + n_b[b], cstart[b+1]) for every
+ * b and [.., nrows) behind the last one -- what a kernel that writes only rows cstart[b] .. + n_b[b] (attention over
+ * compact rows) leaves untouched.  cstart must be ascending (gct_live_rows / gct_key_rows). */
+int gct_zero_gap_rows(float* buf, int64_t ld, int cols, const int32_t* cstart, const int32_t* n_b, int B, int64_t nrows,
+                      void* stream);
 /* dst rows += the compact rows (gradient of rows that were gathered: the encoder's K | V over its visible rows) */
 int gct_scatter_add_quads(const float* src, int64_t ld, const int32_t* quad_list, int64_t nrows, int cols, float* dst,
                           int64_t ldd, int64_t M, void* stream);
