@@ -496,16 +496,13 @@ def worker(a):
                            "parallelism": f"dp{world}"},
                 "ranks": world, "backend": "rccl" if backend == "nccl" else "gloo (host-staged, test rig)",
                 "launcher": launcher,
-                # 3 x forward flops of a FULL-length batch per second of the headline region.  On
-                # MOSES-length batches the step does not execute all of them (zero-gradient decoder rows, masked memory
-                # rows are skipped), so this is a rate of useful work, not of issued flops: the issued rate is the
-                # fixed_len_80 leg's, where nothing can be skipped (`step_tflops_executed_fixed_len_80`)
-                "step_tflops_counting_skipped_rows": round(FLOP_PER_SMILES_STEP[mtype] * value / 1e12, 2),
                 "final_loss_per_sample": round(final_loss, 4),
                 "roofline": roof,
             }
             if fixed is not None:
                 out["fixed_len_80"] = fixed
+                # 3 x forward flops per SMILES x the rate of the leg in which every row is computed: on
+                # MOSES-length batches the step skips the rows that cannot reach the loss, so no such figure is quoted there
                 out["step_tflops_executed_fixed_len_80"] = round(FLOP_PER_SMILES_STEP[mtype] * fixed["value"] / 1e12, 2)
             if alt is not None:
                 out["same_step_fp32_mfma_gemms"] = alt
