@@ -325,7 +325,41 @@ def decode_block(train_model, a, dev, world, fence, reduce_max):
                                       "micro_probe_70_nodes": graphdiag.micro_probe(70, 10)}
         except Exception as exc:                                  # noqa: BLE001
             res["graph_diagnosis"] = {"error": repr(exc)}
+        if int(os.environ.get("RANK", "0")) == 0:
+            res["graph_diagnosis"]["runtime_switches"] = replay_switch_children()
     return res
+
+
+def replay_switch_children(rows=512, budget_s=200.0):
+    """Only when graph replay was the slower mode: the decode comparison of tools/graph_probe.py repeated in CHILD
+    processes (fresh HIP runtimes; this process only waits) under the runtime switches that change where a graph's
+    kernel arguments live and how its nodes are issued, so that the line names the switch that makes the difference on
+    this box.  Bounded: stops starting children after budget_s seconds."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    probe = os.path.join(here, "tools", "graph_probe.py")
+    if not os.path.exists(probe):
+        return {"error": "tools/graph_probe.py is not next to bench.py"}
+    out, t0 = [], time.perf_counter()
+    for ks in ({"HIP_FORCE_DEV_KERNARG": "1"}, {"HIP_FORCE_DEV_KERNARG": "0"}, {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "0"},
+               {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "1"}, {"DEBUG_HIP_GRAPH_BATCH_SIZE": "1"}):
+        if time.perf_counter() - t0 > budget_s:
+            out.append({"env": ks, "skipped": "time budget"})
+            continue
+        env = dict(os.environ)
+        env.update(ks)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        try:
+            p = subprocess.run([sys.executable, probe, "--stage", "knob", "--rows", str(rows)], env=env,
+                               capture_output=True, text=True, timeout=90)
+            line = [l for l in p.stdout.splitlines() if l.startswith("CHILD ")]
+            rec = json.loads(line[-1][6:]) if line else {"error": (p.stderr or p.stdout)[-300:]}
+        except Exception as exc:                                  # noqa: BLE001
+            rec = {"error": repr(exc)}
+        d = rec.get("decode", {}).get(str(rows))
+        out.append({"env": ks, **({"ms_per_token_graph": d["wall_ms_per_token_graph"],
+                                   "ms_per_token_eager": d["wall_ms_per_token_eager"]} if d else rec)})
+    return out
 
 
 # ------------------------------------------------------------------------------------ worker

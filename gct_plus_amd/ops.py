@@ -57,8 +57,10 @@ def _chk(t: torch.Tensor, name: str, dtype=torch.float32):
 #     (the in-place residual-gradient buffer `g` of engine.py is the case that matters);
 #   * join_side() makes the main stream wait for everything (called at the end of each trunk's
 #     backward, before autograd / all-reduce / Adam can touch the gradients).
-# Measured on MI355X (bench.py, B=512): 112.5 ms/step without vs 112.7 ms with the side stream --
-# no gain, so it is OFF by default (GCT_SIDE_STREAM=1 enables it; tests cover both settings).
+# Measured on MI355X (bench.py, B=512): 112.5 ms/step without vs 112.7 ms with the side stream (round 1); with the
+# bf16x6 kernels 49.2 without, 50.3 with, 50.7-50.9 with the side stream at low and the main stream at high priority
+# (round 3: one 144 KB workgroup fills a CU, so a second stream only interleaves whole workgroups and splits the L2)
+# -- no gain, so it is OFF by default (GCT_SIDE_STREAM=1 enables it; tests cover both settings).
 SIDE_ENABLED = os.environ.get("GCT_SIDE_STREAM", "0") != "0"
 _SIDE = {}
 _PENDING = {}

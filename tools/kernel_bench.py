@@ -76,6 +76,36 @@ def decgemm_suite(reps):
             print(f"gemm {name:5s} fwd M={M} K={K} N={N}: {med*1e6:8.1f} us  {fl/med/1e12:6.1f} TF  (best {fl/best/1e12:6.1f})", flush=True)
 
 
+def epi_suite(reps):
+    """What the fused epilogues cost per forward / dgrad GEMM at the training shapes: bias only vs GELU (+ dropout) vs
+    dropout + residual, p = 0 against p = 0.1 (the Philox share)."""
+    dev = "cuda"
+    M = 40960
+    for name, K, N in (("out", 512, 512), ("ffn1", 512, 2048), ("ffn2", 2048, 512)):
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(N * K, device=dev) * K ** -0.5
+        if ops.gemm_get_mode() == ops.GEMM_BF16X6:
+            ops.register_planes(w, ops.split_planes(w))
+        W = w.view(N, K)
+        b, y = torch.randn(N, device=dev), torch.empty(M, N, device=dev)
+        resid, pre = torch.randn(M, N, device=dev), torch.empty(M, N, device=dev)
+        fl = 2.0 * M * K * N
+        cases = [("bias", dict())]
+        for p in (0.0, 0.1):
+            cases.append((f"gelu_drop p={p}", dict(epi=ops.EPI_GELU_DROP, pre=pre, p=p, seed=3, site=1)))
+            cases.append((f"drop_resid p={p}", dict(epi=ops.EPI_DROP_RESID, resid=resid, p=p, seed=3, site=1)))
+        for label, kw in cases:
+            med, best = timeit(lambda: ops.linear_fwd(x, [W], [b], [y], N, **kw), reps)
+            print(f"epi {name:5s} fwd   {label:18s}: {med*1e6:8.1f} us  {fl/med/1e12:6.1f} TF", flush=True)
+        dy, dx = torch.randn(M, N, device=dev), torch.empty(M, K, device=dev)
+        prek = torch.randn(M, K, device=dev)
+        cases = [("store", dict())] + [(f"gelu_bwd p={p}", dict(depi=ops.DEPI_GELU_BWD, pre=prek, p=p, seed=3, site=1))
+                                       for p in (0.0, 0.1)]
+        for label, kw in cases:
+            med, best = timeit(lambda: ops.linear_dgrad([dy], N, M, [W], dx, **kw), reps)
+            print(f"epi {name:5s} dgrad {label:18s}: {med*1e6:8.1f} us  {fl/med/1e12:6.1f} TF", flush=True)
+
+
 def attn_suite(reps, fixed=False):
     dev = "cuda"
     shapes = [("enc", 512, 8, 80, 80, 64, False), ("dec", 512, 8, 81, 81, 64, True), ("cross", 512, 8, 81, 80, 64, False)]
@@ -144,6 +174,8 @@ if __name__ == "__main__":
         gemm_suite(a.reps, a.only.split(",") if a.only else None)
     if "decgemm" in a.suite:
         decgemm_suite(a.reps)
+    if "epi" in a.suite.split(","):
+        epi_suite(a.reps)
     if "attn" in a.suite:
         attn_suite(a.reps)
         attn_suite(a.reps, fixed=True)
