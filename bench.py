@@ -476,6 +476,20 @@ def worker(a):
         fixed = {"steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 3), "value": round(a.batch * world * k2 / dt2, 1),
                  "note": "every sample 80 tokens (no padding): worst case of SURVEY.md 8(d)"}
 
+    # the same step on the headline batches with EVERY decoder row computed in the forward pass (the reference's
+    # forward: logits for padded target positions too, which its ignore_index loss then drops)
+    dense = None
+    if not cpu and not a.no_fixed_len_leg and not a.dense_decoder and not a.fixed_len:
+        a.dense_decoder = True                    # fwd_loss reads the switch at every call
+        k2 = max(3, a.steps // 3)
+        for i in range(2):
+            step(nxt + i)
+        dt2, _ = region(nxt + 2, k2)
+        nxt += 2 + k2
+        a.dense_decoder = False
+        dense = {"steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 3), "value": round(a.batch * world * k2 / dt2, 1),
+                 "note": "forward pass over every decoder row (model.forward without loss_rows); same loss, same gradients"}
+
     # the same step with the GEMMs on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32), for reference: a short
     # further timed region (every rank runs it, so the collectives stay matched)
     alt = None
@@ -533,6 +547,15 @@ def worker(a):
                 "final_loss_per_sample": round(final_loss, 4),
                 "roofline": roof,
             }
+            if not a.dense_decoder:
+                out["rows_not_computed"] = (
+                    "as Train/trainer1.run_epoch runs it: decoder rows whose target is <pad> (ignore_index in the loss) "
+                    "and K/V of padded memory / source rows are not computed; loss, every gradient and the updated "
+                    "parameters equal the dense step's (tests/test_model_gpu.py::test_full_size_batch_512_skip_ignored_"
+                    "vs_oracle); `every_decoder_row` and `fixed_len_80` are the same step without the shortcut / on "
+                    "batches where none applies")
+            if dense is not None:
+                out["every_decoder_row"] = dense
             if fixed is not None:
                 out["fixed_len_80"] = fixed
                 # 3 x forward flops per SMILES x the rate of the leg in which every row is computed: on

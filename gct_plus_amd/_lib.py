@@ -60,6 +60,7 @@ SIGNATURES = {
     "gct_attn_bwd_ws_bytes": (I64, [I32, I32, I32, I32]),
     "gct_key_rows": (I32, [P, I64, I32, I32, P, P, P, P, P, P, P]),
     "gct_attn_mask_pack": (I32, [P, I64, I64, I32, I32, I32, P, P, P]),
+    "gct_trg_mask_tokens": (I32, [P, I64, I64, I32, I32, P, P]),
     "gct_reparam_fwd": (I32, [P, P, P, P, P, I64, U64, U32, P]),
     "gct_reparam_bwd": (I32, [P, P, P, P, P, P, P, I64, P]),
     "gct_kld_fwd": (I32, [P, P, P, P, I64, P]),
@@ -84,7 +85,7 @@ SIGNATURES = {
     "gct_graph_census": (I32, [P, P]),
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _lib = None
 
 

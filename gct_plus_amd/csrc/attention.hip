@@ -1348,6 +1348,34 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const uint8_t* __restric
   bits[i] = word;
 }
 
+// decoder self-attention mask straight from the token ids (reference Model/modules.py:47-58 without cond2dec):
+// out[b][q][k] = (tok[b][k] != pad) & (k <= q) & (pad & 1) -- the reference multiplies its no-peek pattern by pad_idx
+// and ANDs it with the bool pad mask, so only bit 0 of pad_idx survives.  One thread per four keys.
+__global__ __launch_bounds__(256) void trg_mask_tokens_kernel(const int64_t* __restrict__ tok, int64_t ld, int64_t pad,
+                                                              int B, int T, uint8_t* __restrict__ out) {
+  const int64_t n = (int64_t)B * T * T;
+  const int64_t e0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e0 >= n) return;
+  const uint8_t on = (uint8_t)(pad & 1);
+  uint8_t v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t e = e0 + j;
+    v[j] = 0;
+    if (e < n) {
+      const int k = (int)(e % T);
+      const int64_t bq = e / T;
+      const int q = (int)(bq % T), b = (int)(bq / T);
+      v[j] = (tok[(int64_t)b * ld + k] != pad && k <= q) ? on : (uint8_t)0;
+    }
+  }
+  if (e0 + 3 < n) {
+    *reinterpret_cast<uchar4*>(out + e0) = make_uchar4(v[0], v[1], v[2], v[3]);
+  } else {
+    for (int j = 0; j < 4 && e0 + j < n; ++j) out[e0 + j] = v[j];
+  }
+}
+
 #ifdef GCT_STAMPS
 unsigned long long* g_attn_stamps = nullptr;   // tools/attn_stamps.hip
 #endif
@@ -1473,6 +1501,18 @@ extern "C" int gct_attn_mask_pack(const uint8_t* mask, int64_t mask_sb, int64_t 
                        rows * MASK_W, mask_sq == 0 ? 0 : MASK_W, B, ntr, Lq, Lk, tiles);
     GCT_LAUNCH_CHECK("attn_mask_pack (tiles)");
   }
+  return GCT_OK;
+}
+
+extern "C" int gct_trg_mask_tokens(const int64_t* tokens, int64_t ld_tok, int64_t pad, int B, int T, uint8_t* out,
+                                   void* stream) {
+  GCT_CHECK_ARG(tokens && out && B >= 0 && T > 0 && ld_tok >= T && ((uintptr_t)out & 3u) == 0,
+                "trg_mask_tokens: bad args");
+  const int64_t n4 = ((int64_t)B * T * T + 3) / 4;
+  if (n4 == 0) return GCT_OK;
+  hipLaunchKernelGGL(trg_mask_tokens_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     tokens, ld_tok, pad, B, T, out);
+  GCT_LAUNCH_CHECK("trg_mask_tokens");
   return GCT_OK;
 }
 

@@ -666,6 +666,18 @@ def _mask_strides(mask_u8, B, Lq, Lk):
                         f"(B={B}, Lq={Lq}, Lk={Lk})")
 
 
+def trg_mask_u8(target: torch.Tensor, pad_id: int) -> torch.Tensor:
+    """uint8 [B,T,T] form of Model.modules.get_trg_mask(target, pad_id, use_cond2dec=False) built from the token ids in
+    one launch (reference Model/modules.py:47-58 builds an int64 [B,T,T] tensor: 27 MB at B = 512).  Nonzero = the
+    query may attend, exactly where the reference's mask is nonzero (including its `* pad_idx` quirk)."""
+    _chk(target, "trg_mask.target", torch.int64)
+    B, T = target.shape
+    out = torch.empty(B, T, T, dtype=torch.uint8, device=target.device)
+    check(_L().gct_trg_mask_tokens(_p(target), target.stride(0), int(pad_id), B, T, _p(out), _st()),
+          "gct_trg_mask_tokens")
+    return out
+
+
 def to_mask_u8(mask: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     """Reference masks are bool [B,1,Lk] (Model/modules.py:38-44) or int64 [B,T,T]
     (modules.py:47-58); the kernels take uint8 (0 = masked)."""

@@ -37,7 +37,7 @@ extern "C" {
 #define GCT_ERR_ARG (-1)  /* bad shape / alignment / null pointer            */
 #define GCT_ERR_HIP (-2)  /* a HIP runtime call failed (launch error)        */
 
-#define GCT_ABI_VERSION 10
+#define GCT_ABI_VERSION 11
 
 int gct_version(void);
 const char* gct_last_error(void);
@@ -265,6 +265,11 @@ int gct_dropout_bwd(const float* dout, float* dy, int64_t rows, int cols, float 
  * are back.  The kernels compute the same word themselves when tbits is NULL. */
 int gct_attn_mask_pack(const uint8_t* mask, int64_t mask_sb, int64_t mask_sq, int B, int Lq, int Lk,
                        uint32_t* bits, uint32_t* tiles, void* stream);
+/* The decoder's self-attention mask straight from the token ids: the uint8 form of get_trg_mask(target, pad, False)
+ * (Model/modules.py:17-30, 47-58: pad mask & no-peek pattern * pad_idx, so out[b][q][k] = (tokens[b][k] != pad) &
+ * (k <= q) & (pad & 1)) in ONE launch instead of the reference's int64 [B][T][T] tensor and its ~10 elementwise
+ * launches.  tokens: [B] rows of T ids, leading dimension ld_tok; out: uint8 [B][T][T], 4-byte aligned. */
+int gct_trg_mask_tokens(const int64_t* tokens, int64_t ld_tok, int64_t pad, int B, int T, uint8_t* out, void* stream);
 int gct_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
                  int64_t ldv, const uint32_t* mbits, int64_t mb_sb, int64_t mb_sq,
                  float* o, int64_t ldo, float* lse, float* probs, int B, int H, int Lq, int Lk,

@@ -771,3 +771,19 @@ def test_wgrad_over_nonzero_row_tiles(ops):
     close(out["tiles"][0], ref_w, tol, 1e-4, "wgrad over listed tiles")
     close(out["tiles"][1], ref_b, tol, 1e-4, "bias grad over listed tiles")
     close(out["tiles"][0], out["dense"][0], 2e-6 * float(ref_w.abs().max()), 1e-5, "listed vs dense (summation split differs)")
+
+
+@pytest.mark.parametrize("pad", [0, 1, 2, 3])
+def test_trg_mask_from_tokens_equals_the_reference_mask(ops, pad):
+    """gct_trg_mask_tokens against the ORACLE's get_trg_mask (reference Model/modules.py:17-30, 47-58), nonzero pattern
+    bit for bit -- including the reference's `no-peek * pad_idx` quirk (an even pad index blanks the whole mask) -- on a
+    contiguous id matrix, on the trainer's trg[:, :-1] view and on sizes that are not multiples of four."""
+    from oracle import gct_oracle as O
+    g = torch.Generator().manual_seed(pad)
+    for B, T in ((5, 21), (3, 81), (7, 13), (1, 1)):
+        full = torch.randint(0, 6, (B, T + 1), generator=g)
+        for tok in (full[:, :-1], full[:, :-1].contiguous()):
+            want = O.get_trg_mask(tok, pad, False, None) != 0
+            got = ops.trg_mask_u8(tok.to(DEV), pad)
+            assert got.dtype == torch.uint8 and tuple(got.shape) == (B, T, T)
+            assert torch.equal(got.cpu() != 0, want), (pad, B, T)
