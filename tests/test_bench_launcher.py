@@ -63,3 +63,14 @@ def test_plain_gpus2_real_model_shared_gpu():
     assert out["roofline"] is None or "kernel" in out["roofline"]
     assert out["fixed_len_80"]["ms_per_step"] > 0
     assert out["final_loss_per_sample"] == out["final_loss_per_sample"]      # not NaN
+
+
+def test_replay_switch_children_never_raise():
+    """bench.py's slow-replay diagnosis starts child processes; without a GPU (or past its time budget) it must come
+    back with one record per runtime switch -- an error text or 'skipped' -- and never raise into the bench line."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    recs = mod.replay_switch_children(budget_s=-1.0)          # budget already spent: nothing is started
+    assert len(recs) == 5 and all(r.get("skipped") == "time budget" and "env" in r for r in recs)
