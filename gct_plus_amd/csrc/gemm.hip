@@ -1212,6 +1212,17 @@ int launch_x6_tail_split(const GemmArgs& g, hipStream_t st, float* ws, int64_t w
   if (e.pre) e.pre += m1 * g.ldc;
   // pre_in read through the quad map keeps the forward's row space: the tail finds its rows through row_base
   if (e.pre_in && !(g.pre_rows > 0 && g.quad_map)) e.pre_in += m1 * g.ldc;
+  {
+    // K <= 1 024 and a short tail: the tail rows on 64 x 128 tiles (gemm_x6s_kernel, up to two per CU) finish with
+    // their own epilogue -- no slabs, no fix-up launch (48.6 -> 48.2 ms per step with the forward launches alone)
+    static const int small_cap = getenv("GCT_X6_TAIL_SMALL") ? atoi(getenv("GCT_X6_TAIL_SMALL")) : 512;  // A/B switch: 0 = off
+    static const int small_dg = getenv("GCT_X6_TAIL_SMALL_DGRAD") ? atoi(getenv("GCT_X6_TAIL_SMALL_DGRAD")) : 1;
+    const int64_t small = ((m2 + SBM - 1) / SBM) * ((g.N + SBN - 1) / SBN);
+    if (nkt <= 32 && small <= small_cap) {
+      if (MODE == X6_FWD && x6s_ok(e, true)) return launch_x6s<X6_FWD>(e, st);
+      if (MODE == X6_DGRAD && small_dg && x6s_dgrad_ok(e, true)) return launch_x6s<X6_DGRAD>(e, st);
+    }
+  }
   GemmArgs p = e;
   p.nsplit = best;
   p.ksplit = ((nkt + best - 1) / best) * XBK;
