@@ -647,8 +647,9 @@ def roofline(prof, dt):
                 "avg_launch_us": kern[dom].get("avg_kernel_us", kern[dom]["avg_us"]),
                 "launches": kern[dom].get("kernel_launches", kern[dom]["launches"]),
                 "gemm_calls": kern[dom]["launches"], "avg_call_us": kern[dom]["avg_us"],
-                "note": "avg_launch_us = time of all forward GEMM calls / gemm_x6_kernel<FWD> launches (a "
-                        "tail-balanced call launches the kernel twice plus a small fix-up kernel, which is "
+                "note": "avg_launch_us = time of all forward GEMM calls / bf16x6 forward kernel launches (a "
+                        "tail-balanced call launches the 128x256-tile kernel for the full rounds and the 64x128-tile "
+                        "kernel -- or a K-split launch plus a small fix-up kernel -- for the tail rows, all "
                         "inside the bracket); achieved/peak in fp32-equivalent (algorithmic) FLOP/s, peak = dense "
                         f"bf16 {PEAK_BF16_MFMA_TFLOPS} / 6 partial products, so frac = MFMA utilisation; on the pipe "
                         f"itself: {round(6 * kern[dom]['tflops'], 1)} of {PEAK_BF16_MFMA_TFLOPS} bf16 TFLOP/s; "
