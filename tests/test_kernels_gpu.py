@@ -787,3 +787,45 @@ def test_trg_mask_from_tokens_equals_the_reference_mask(ops, pad):
             got = ops.trg_mask_u8(tok.to(DEV), pad)
             assert got.dtype == torch.uint8 and tuple(got.shape) == (B, T, T)
             assert torch.equal(got.cpu() != 0, want), (pad, B, T)
+
+
+def test_tail_rows_on_the_small_tile_kernel_vs_fp64(ops):
+    """Tail-balanced bf16x6 launches whose tail rows run on gemm_x6s_kernel (K <= 1024, <= 512 tiles of 64 x 128): the
+    forward with two weight / output segments, the forward with the dropout + residual epilogue (p = 0: comparable with
+    fp64), and the
+    dgrad mode of the small kernel with a two-segment dY (K' = 1024) accumulating into an existing buffer -- 155 row
+    tiles like the decoder's compact rows at batch 512.  Head and tail rows against fp64; exactly two bf16x6 kernel
+    launches per call (no K-split, no fix-up)."""
+    M, K, nper, nseg = 155 * 128, 512, 512, 2
+    N = nper * nseg
+    x = rnd(M, K, seed=1)
+    ws = [rnd(nper, K, seed=10 + s, scale=K ** -0.5) for s in range(nseg)]
+    bs = [rnd(nper, seed=20 + s) for s in range(nseg)]
+    resid = rnd(M, N, seed=4)
+    flat, wv = _planes_for(ops, ws)
+    try:
+        xd = x.to(DEV)
+        y = torch.empty(M, N, device=DEV)
+        outs = [y[:, s * nper:] for s in range(nseg)]
+        k0 = ops._L().gct_gemm_x6_kernel_launches()
+        ops.linear_fwd(xd, wv, [b.to(DEV) for b in bs], outs, N)
+        assert ops._L().gct_gemm_x6_kernel_launches() == k0 + 2
+        ref = x.double() @ torch.cat(ws).double().t() + torch.cat(bs).double()
+        close(y, ref, 2e-5, 2e-5, "forward (two segments), tail on small tiles")
+        y1 = torch.empty(M, nper, device=DEV)                 # fused epilogues take one segment: 155 x 2 tiles
+        k0 = ops._L().gct_gemm_x6_kernel_launches()
+        ops.linear_fwd(xd, wv[:1], [bs[0].to(DEV)], [y1], nper, epi=ops.EPI_DROP_RESID, resid=resid[:, :nper].contiguous().to(DEV), p=0.0)
+        assert ops._L().gct_gemm_x6_kernel_launches() == k0 + 2
+        close(y1, ref[:, :nper] + resid[:, :nper].double(), 2e-5, 2e-5, "forward (dropout + residual epilogue), tail on small tiles")
+        # dgrad: dX[M, K] (+)= dY[M, 2 x 512] @ [W0; W1]  -- N(out) = 512 -> 155 x 2 tiles = 256 + 54
+        dy = rnd(M, N, seed=5).to(DEV)
+        dys = [dy[:, s * nper:] for s in range(nseg)]
+        base = rnd(M, K, seed=6)
+        dx = base.to(DEV).clone()
+        k0 = ops._L().gct_gemm_x6_kernel_launches()
+        ops.linear_dgrad(dys, N, M, wv, dx, depi=ops.DEPI_ACCUM)
+        assert ops._L().gct_gemm_x6_kernel_launches() == k0 + 2
+        refd = base.double() + dy.cpu().double() @ torch.cat(ws).double()
+        close(dx, refd, 4e-5, 2e-5, "dgrad, tail on small tiles")
+    finally:
+        ops.unregister_planes(flat)
