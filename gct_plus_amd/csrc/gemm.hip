@@ -1308,6 +1308,17 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
       }
     }
   }
+  if (A_KC && !B_KC && gemm_mode() == GCT_GEMM_BF16X6 && g.epi >= EPI_D0 && g.epi < EPI_SLAB) {
+    // the same for dgrad launches (training at small batches): few 128 x 256 tiles, enough 64 x 128 ones
+    static const int x6s_dg = getenv("GCT_X6S_DGRAD") ? atoi(getenv("GCT_X6S_DGRAD")) : 1;              // A/B switch
+    const int64_t big = ((g.M + XBM - 1) / XBM) * ((g.N + XBN - 1) / XBN);
+    const int64_t small = ((g.M + SBM - 1) / SBM) * ((g.N + SBN - 1) / SBN);
+    const int64_t nkt_ = g.K / XBK;
+    if (x6s_dg && big <= 160 && small >= 96 && small <= (nkt_ <= 16 ? 512 : 256) && nkt_ <= 32 && x6s_dgrad_ok(g, vec)) {
+      ++g_gemm_launches[1];
+      return launch_x6s<X6_DGRAD>(g, st);
+    }
+  }
   // narrow outputs (the vocabulary head, N = 28-31): the ragged panel kernel, exact fp32 MFMA, M / 32 workgroups
   if (A_KC && B_KC && vec && g.N <= 32 && g.K % 256 == 0 && g.epi == GCT_EPI_BIAS && g.nsplit == 1 && g.b_nper >= g.N &&
       g.c_nper >= g.N && g.M >= 1 && g.lda * 4 * 33 < (1ll << 31) && g.ldb * 4 * 33 < (1ll << 31) && g.M < (1ll << 36)) {
