@@ -1256,7 +1256,7 @@ int x6_splitk_all_plan(int64_t M, int64_t N, int64_t K) {
 template <int MODE>
 int launch_x6_splitk_all(const GemmArgs& g, hipStream_t st, float* ws, int64_t ws_bytes, int* taken) {
   *taken = 0;
-  if (MODE != X6_FWD || g.nsplit != 1 || !ws || !gct_aligned16(ws)) return GCT_OK;
+  if ((MODE != X6_FWD && MODE != X6_DGRAD) || g.nsplit != 1 || !ws || !gct_aligned16(ws)) return GCT_OK;
   const int64_t sp = x6_splitk_all_plan(g.M, g.N, g.K), nkt = g.K / XBK;
   if (sp < 2 || sp * g.M * g.N * (int64_t)sizeof(float) > ws_bytes) return GCT_OK;
   GemmArgs p = g;
@@ -1317,6 +1317,16 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
     if (x6s_dg && big <= 160 && small >= 96 && small <= (nkt_ <= 16 ? 512 : 256) && nkt_ <= 32 && x6s_dgrad_ok(g, vec)) {
       ++g_gemm_launches[1];
       return launch_x6s<X6_DGRAD>(g, st);
+    }
+    // ... and a long reduction over few tiles (K' = 1 536 / 2 048 at batch 64): K split over the whole problem + fix-up
+    static const int dg_splitk = getenv("GCT_X6_DGRAD_SPLITK") ? atoi(getenv("GCT_X6_DGRAD_SPLITK")) : 1;  // A/B switch
+    if (dg_splitk && x6_ok<X6_DGRAD>(g, vec)) {
+      int taken = 0;
+      const int rc = launch_x6_splitk_all<X6_DGRAD>(g, st, skinny_ws, ws_bytes, &taken);
+      if (rc || taken) {
+        if (taken) ++g_gemm_launches[1];
+        return rc;
+      }
     }
   }
   // narrow outputs (the vocabulary head, N = 28-31): the ragged panel kernel, exact fp32 MFMA, M / 32 workgroups
@@ -1557,7 +1567,10 @@ extern "C" int64_t gct_linear_fwd_ws_bytes(int64_t M, int K, int Ntot) {
 extern "C" int64_t gct_linear_dgrad_ws_bytes(int64_t M, int Ntot, int K) {
   int64_t m1 = 0;
   const int s = x6_tail_plan(M, K, Ntot, &m1);       // dx is [M][K], reduced over Ntot
-  return (s > 1 ? (int64_t)s * (M - m1) * K * (int64_t)sizeof(float) : 0) + 256;
+  const int64_t tail = s > 1 ? (int64_t)s * (M - m1) * K * (int64_t)sizeof(float) : 0;
+  const int64_t sp = x6_splitk_all_plan(M, K, Ntot);  // few tiles, long reduction: K split over the whole problem
+  const int64_t all = sp > 1 ? sp * M * K * (int64_t)sizeof(float) : 0;
+  return (tail > all ? tail : all) + 256;
 }
 
 static int linear_dgrad_impl(const float* dy0, const float* dy1, const float* dy2, int64_t lddy,
