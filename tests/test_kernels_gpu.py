@@ -829,3 +829,37 @@ def test_tail_rows_on_the_small_tile_kernel_vs_fp64(ops):
         close(dx, refd, 4e-5, 2e-5, "dgrad, tail on small tiles")
     finally:
         ops.unregister_planes(flat)
+
+
+@pytest.mark.parametrize("M,Kp,N,depi,launches", [(5120, 512, 512, "store", 1),      # 80 tiles of 128 x 256 -> 320 small tiles
+                                                  (5120, 2048, 512, "gelu", 1),       # long reduction over 80 tiles: K split 3 ways + fix-up
+                                                  (2560, 1536, 512, "accum", 1)])     # three dY segments, 40 tiles, K split 6 ways
+def test_dgrad_routes_for_few_tiles_vs_fp64(ops, M, Kp, N, depi, launches):
+    """dgrad launches of a training step at batch 32-64: too few 128 x 256 tiles to fill the chip.  K' <= 1024 takes the
+    small-tile kernel's dgrad mode, a long reduction takes the K-split-over-the-whole-problem route (both bf16x6: one
+    kernel launch counted).  Against fp64, with the GELU-backward and accumulate epilogues."""
+    nseg = 3 if Kp == 1536 else 1
+    nper = Kp // nseg
+    dy = rnd(M, Kp, seed=1)
+    ws = [rnd(nper, N, seed=10 + s, scale=Kp ** -0.5) for s in range(nseg)]
+    pre = rnd(M, N, seed=3)
+    base = rnd(M, N, seed=4)
+    flat, wv = _planes_for(ops, ws)
+    try:
+        dyd = dy.to(DEV)
+        dys = [dyd[:, s * nper:] for s in range(nseg)]
+        dx = base.to(DEV).clone()
+        k0 = ops._L().gct_gemm_x6_kernel_launches()
+        kw = {"store": {}, "gelu": dict(depi=ops.DEPI_GELU_BWD, pre=pre.to(DEV), p=0.0),
+              "accum": dict(depi=ops.DEPI_ACCUM)}[depi]
+        ops.linear_dgrad(dys, Kp, M, wv, dx, **kw)
+        assert ops._L().gct_gemm_x6_kernel_launches() == k0 + launches
+    finally:
+        ops.unregister_planes(flat)
+    ref = dy.double() @ torch.cat(ws).double()
+    if depi == "gelu":
+        u = pre.double()
+        ref = ref * (0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi))
+    elif depi == "accum":
+        ref = ref + base.double()
+    close(dx, ref, 4e-5, 2e-5, f"dgrad {depi} M={M} K'={Kp}")
