@@ -179,8 +179,10 @@ int gct_linear_dgrad_p(const float* dy0, const float* dy1, const float* dy2, int
  * mask of compact quad q from original quad quad_map[q].  pre_rows == 0: pre is compact like dy / dx; pre_rows > 0:
  * pre keeps the forward's row space (pre_rows rows) and is read through the quad map (no gathered copy needed). */
 /* ws of gct_linear_dgrad_p (nullable): >= gct_linear_dgrad_ws_bytes(M, nseg*nper, K).  With a workspace the
- * bf16x6 forward / dgrad launches balance a partial last round of tiles (K-split tail launch + fix-up kernel);
- * gct_linear_fwd_ws_bytes covers the forward (skinny split-K or tail slabs, whichever the launch would use). */
+ * bf16x6 forward / dgrad launches balance a partial last round of tiles (the tail rows as a second launch: on 64 x 128
+ * tiles when the reduction is <= 1024 long, else K-split into slabs + a fix-up kernel) and split a long reduction over
+ * few tiles across the whole chip; gct_linear_fwd_ws_bytes covers the forward (skinny split-K or tail slabs, whichever
+ * the launch would use).  Without one every launch is a single kernel. */
 int64_t gct_linear_dgrad_ws_bytes(int64_t M, int Ntot, int K);
 
 /* Zero-gradient rows.  Under an ignore_index loss the rows of padded target positions carry exactly zero
