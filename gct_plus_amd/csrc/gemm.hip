@@ -454,6 +454,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
 // K = 512 shapes, +1 % on the step; -DGCT_EPI_PLAIN restores ordinary stores)
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void epi_store4(float* p, const float (&x)[4]) {
+#ifdef GCT_LAB_NO_EPI_STORE   // tools/gemm_lab.hip: arithmetic kept alive, (almost) nothing stored
+  if (x[0] != 123456.789f) return;
+#endif
 #ifdef GCT_EPI_PLAIN
   *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
 #else
@@ -465,6 +468,9 @@ struct FastEpi {
   const GemmArgs& g;
   // number of extra float4 reads per patch row this epilogue needs (resid / accumulate / pre_in)
   __device__ __forceinline__ bool needs_extra() const {
+#ifdef GCT_LAB_NO_EPI_MATH
+    return false;
+#endif
     return g.epi == GCT_EPI_DROP_RESID || g.epi == EPI_D0 + GCT_DEPI_ACCUM ||
            g.epi == EPI_D0 + GCT_DEPI_GELU_BWD;
   }
@@ -496,7 +502,11 @@ struct FastEpi {
   __device__ __forceinline__ void apply(float4 (&v)[4], const float4 (&ex)[4], int64_t row0,
                                         int64_t col0, float* cbase, int64_t cloc, float4 bias) const {
     // v[rr] = 4 consecutive columns (col0..col0+3) of row row0+rr; row0 % 4 == 0
+#ifdef GCT_LAB_NO_EPI_MATH    // tools/gemm_lab.hip: raw accumulators
+    const int epi = EPI_D0 + GCT_DEPI_STORE;
+#else
     const int epi = g.epi;
+#endif
     uint4 bits[2];   // one Philox call per 4 rows x 2 columns (col0 % 4 == 0)
     const bool rng = g.thr != 0u && (epi == GCT_EPI_GELU_DROP || epi == GCT_EPI_DROP_RESID ||
                                      epi == EPI_D0 + GCT_DEPI_GELU_BWD);
@@ -847,6 +857,19 @@ gemm_f32_fast_kernel(const GemmArgs g) {
 
 int64_t g_x6_kernel_launches = 0;   // gemm_x6_kernel launches (a tail-balanced call makes two)
 #include "gemm_x6.inc"
+#ifdef GCT_LAB_X6P
+// tools/gemm_lab.hip only: the persistent stream-K form of the forward / dgrad kernels (round-4 experiment, measured and
+// not adopted: profiles/r04_gemm_experiment_persistent_*.log).  Nothing of it is compiled into the library.
+#include "../../tools/gemm_x6p.inc"
+constexpr int X6P_SYNC_SLOTS = 32;
+int g_x6p_on = 0;
+int* g_x6p_counters = nullptr;
+unsigned g_x6p_seq = 0;
+inline int* x6p_counter_slot() {
+  if (!g_x6p_counters) return nullptr;
+  return g_x6p_counters + (size_t)((g_x6p_seq++) % X6P_SYNC_SLOTS) * 256;
+}
+#endif
 
 // =====================================================================================
 // SKINNY-M forward kernel (KV-cached decode: M = batch rows per step = 512): 64x64 tiles, 4 waves
@@ -1389,6 +1412,15 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
     constexpr int MODE = A_KC ? (B_KC ? X6_FWD : X6_DGRAD) : X6_WGRAD;
     if ((A_KC || !B_KC) && x6_ok<MODE>(g, vec)) {
       ++g_gemm_launches[1];
+#ifdef GCT_LAB_X6P
+      if constexpr (MODE != X6_WGRAD) {
+        if (g_x6p_on && x6p_ok<MODE>(g, vec)) {
+          int taken = 0;
+          const int rc = launch_x6p<MODE>(g, st, skinny_ws, ws_bytes, x6p_counter_slot(), &taken);
+          if (rc || taken) return rc;
+        }
+      }
+#endif
       return launch_x6_tail_split<MODE>(g, st, skinny_ws, ws_bytes);
     }
   }
@@ -1527,6 +1559,18 @@ extern "C" int gct_gemm_set_mode(int mode) {
   return GCT_OK;
 }
 extern "C" int gct_gemm_get_mode(void) { return gemm_mode(); }
+#ifdef GCT_LAB_X6P
+extern "C" int gct_gemm_set_persistent(int on) {
+  g_x6p_on = on ? 1 : 0;
+  return GCT_OK;
+}
+extern "C" int gct_gemm_set_sync_buffer(int32_t* buf, int64_t bytes) {
+  GCT_CHECK_ARG(!buf || bytes >= (int64_t)X6P_SYNC_SLOTS * 256 * 4, "gemm_set_sync_buffer: need %d bytes, zero-initialised",
+                X6P_SYNC_SLOTS * 256 * 4);
+  g_x6p_counters = buf;
+  return GCT_OK;
+}
+#endif
 extern "C" int64_t gct_gemm_x6_kernel_launches(void) { return g_x6_kernel_launches; }
 extern "C" int gct_gemm_launch_counts(int64_t* out2) {
   GCT_CHECK_ARG(out2, "gemm_launch_counts: null");

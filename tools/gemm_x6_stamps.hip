@@ -1,5 +1,6 @@
 // Diagnostic build of the bf16x6 GEMM kernel with s_memtime stamps per segment (never shipped):
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DGCT_STAMPS tools/gemm_x6_stamps.hip -o tools/_build/gemm_x6_stamps
+#define GCT_LAB_X6P 1
 #include "../gct_plus_amd/csrc/capi.hip"
 #include "../gct_plus_amd/csrc/gemm.hip"
 #include <vector>
@@ -9,7 +10,7 @@ int gct_reduce_slabs_seg2(const float*, int, int64_t, float*, float*, float*, in
 int gct_colsum(const float*, const float*, const float*, int64_t, int64_t, int, int, float*, float*, float*, float*, hipStream_t) { return 0; }
 int64_t gct_colsum_ws_floats(int64_t, int64_t) { return 0; }
 
-static void run(int64_t M, int K, int N, int epi) {
+static void run(int64_t M, int K, int N, int epi, int persistent = 0) {
   float *x, *w, *b, *y, *pre;
   uint16_t* wp;
   unsigned long long* st;
@@ -33,6 +34,29 @@ static void run(int64_t M, int K, int N, int epi) {
   g.stamps = st;
   const int64_t tiles = ((M + 127) / 128) * ((N + 255) / 256);
   hipFuncSetAttribute((const void*)gemm_x6_kernel<X6_FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
+  if (persistent) {
+    static int32_t* sync = nullptr;
+    static float* wsp = nullptr;
+    if (!sync) { hipMalloc(&sync, 32 * 256 * 4); hipMemset(sync, 0, 32 * 256 * 4); gct_gemm_set_sync_buffer(sync, 32 * 256 * 4); hipMalloc(&wsp, 64 << 20); }
+    gct_gemm_set_persistent(1);
+    for (int rep = 0; rep < 3; ++rep) {
+      hipMemset(st, 0, 64 * 8 * 8 * 8);
+      int taken = 0;
+      launch_x6p<X6_FWD>(g, 0, wsp, 64 << 20, sync, &taken);
+      hipDeviceSynchronize();
+    }
+    std::vector<unsigned long long> hs(64 * 8 * 8);
+    hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
+    double seg[8] = {0};
+    for (int wv = 0; wv < 64 * 8; ++wv) for (int i = 0; i < 8; ++i) seg[i] += (double)hs[wv * 8 + i] / (64 * 8);
+    double tot = 0; for (int i = 0; i < 8; ++i) tot += seg[i];
+    const double ntile = (double)tiles / 256.0;
+    const char* nm[8] = {"steady iterations", "1st iter after end", "2nd iter after end", "3rd iter after end", "partial hand-off", "epilogue halves", "barrier + reload", "-"};
+    printf("PERSISTENT M=%ld K=%d N=%d epi=%d: wave lifetime %.0f cycles, %.2f tiles per workgroup, k-tiles %d\n", (long)M, K, N, epi, tot, ntile, K / 32);
+    for (int i = 0; i < 7; ++i) printf("   %-20s %9.0f cyc  %5.1f %%   (%.0f per tile)\n", nm[i], seg[i], 100 * seg[i] / tot, seg[i] / ntile);
+    hipFree(x); hipFree(w); hipFree(b); hipFree(y); hipFree(pre); hipFree(wp); hipFree(st);
+    return;
+  }
   for (int rep = 0; rep < 3; ++rep) {
     hipMemset(st, 0, 64 * 8 * 8 * 8);
     hipLaunchKernelGGL((gemm_x6_kernel<X6_FWD>), dim3((unsigned)tiles), dim3(512), X_LDS_BYTES, 0, g);
@@ -54,5 +78,9 @@ int main() {
   run(40960, 512, 2048, GCT_EPI_GELU_DROP);
   run(40960, 2048, 512, GCT_EPI_DROP_RESID);
   run(40960, 512, 512, GCT_EPI_DROP_RESID);
+  run(40960, 512, 2048, GCT_EPI_BIAS, 1);
+  run(40960, 512, 2048, GCT_EPI_GELU_DROP, 1);
+  run(40960, 2048, 512, GCT_EPI_DROP_RESID, 1);
+  run(40960, 512, 512, GCT_EPI_DROP_RESID, 1);
   return 0;
 }
