@@ -64,6 +64,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the short fp32-MFMA-mode comparison run")
     ap.add_argument("--no-fixed-len-leg", action="store_true", help="skip the short fixed_len_80 region")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode block (configs[4] metric)")
+    ap.add_argument("--no-model-types", action="store_true", help="skip the short legs of the other three model types")
+    ap.add_argument("--no-trainer-loop", action="store_true", help="skip the Train.trainer1.run_epoch legs")
     ap.add_argument("--decode-n", type=int, default=4096, help="sequences decoded per GPU (the sampler's n is a free parameter)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo only for the launcher tests")
@@ -181,10 +183,11 @@ def selftest_workload(a, dev, world, rank):
         ys = batch["trg"][:, 1:].reshape(-1)
         return nn.functional.cross_entropy(logits.reshape(-1, vt), ys, ignore_index=synthetic.PAD_ID,
                                            reduction="sum")
+    fwd_loss.model = model
     return inner, opt, fwd_loss
 
 
-def hip_workload(a, dev, world, rank):
+def hip_workload(a, dev, world, rank, mtype=None):
     import torch
     from gct_plus_amd import synthetic
     from gct_plus_amd.Model import forward_propagation, model_dict
@@ -192,7 +195,7 @@ def hip_workload(a, dev, world, rank):
     from gct_plus_amd.dp import FlatDataParallel
     from gct_plus_amd.optim import FusedAdam
 
-    mtype = a.model_type
+    mtype = mtype or a.model_type
     vs, vt = synthetic.vocab_sizes(mtype)
     nc = synthetic.n_conds(mtype)
     dims = dict(N=2, d_model=64, dff=128, h=4, latent_dim=16) if a.tiny else \
@@ -218,6 +221,7 @@ def hip_workload(a, dev, world, rank):
         ys_cond = batch["dconds"].unsqueeze(2).contiguous().view(-1, nc, 1) if nc else None
         loss, _, _, _ = loss_function(beta, prop, mol, ys_cond, ys, mu, lv, False, pad_id)
         return loss
+    fwd_loss.model = model            # the data-parallel wrapper at N > 1 (what a trainer calls), else the model itself
     return inner, opt, fwd_loss
 
 
@@ -362,6 +366,145 @@ def decode_block(train_model, a, dev, world, fence, reduce_max):
     return res
 
 
+def multi_rank_report(a, dpm, inner, host, ops, dev, world, rank, cpu, step, region, nxt):
+    """What a first run on N real GPUs needs to be read without a debugger (every rank takes part; rank 0 reports):
+    who is there (rank -> device), how the gradient exchange went (buckets launched from inside the backward pass vs at
+    its end, device time the compute stream waited for the exchange), what the host spent per step, whether the ranks
+    still hold bit-identical parameters, and the same step with the in-backward launches switched off."""
+    import statistics
+    import torch
+    import torch.distributed as dist
+    if cpu:
+        ident = {"rank": rank, "device": "cpu", "pid": os.getpid()}
+    else:
+        pr = torch.cuda.get_device_properties(dev)
+        ident = {"rank": rank, "device": f"cuda:{dev.index}", "name": pr.name, "pid": os.getpid(),
+                 "uuid": str(getattr(pr, "uuid", "")), "pci_bus_id": getattr(pr, "pci_bus_id", None),
+                 "visible": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")}
+    mine = {"identity": ident,
+            "host_ms_per_step": round(host["s"] / max(host["n"], 1) * 1e3, 3),
+            "host_blocked_in_readback_ms_per_step": round(ops.HOST_BLOCKED_S[0] / max(host["n"], 1) * 1e3, 3) if ops else None,
+            "exchange": dpm.diag_summary() if dpm is not None else None}
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    # bit-identical parameters on every rank: MAX - MIN of an integer checksum of the flat parameter buffer
+    with torch.no_grad():
+        flat = inner.flat_params() if getattr(inner, "_gct_flat", None) is not None else \
+            torch.cat([p.detach().reshape(-1) for p in inner.parameters()])
+        cs = flat.view(torch.int32).to(torch.int64).sum().reshape(1)
+        hi, lo = cs.clone(), cs.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    # A/B: the same step with every bucket launched from the end-of-backward callback (nothing overlapped)
+    ab = None
+    if dpm is not None:
+        dpm.overlap = False
+        step(nxt)
+        dt2, _ = region(nxt + 1, 5)
+        dpm.overlap = True
+        ab = {"steps": 5, "ms_per_step": round(dt2 / 5 * 1e3, 3)}
+    ex = [e["exchange"] for e in every if e and e.get("exchange")]
+    waits = [e["exposed_wait_ms_median"] for e in ex if e.get("exposed_wait_ms_median") is not None]
+    return {"ranks_seen": len([e for e in every if e]), "identities": [e["identity"] for e in every if e],
+            "distinct_devices": len({(e["identity"].get("uuid") or e["identity"].get("pci_bus_id") or e["identity"]["device"])
+                                     for e in every if e}),
+            "host_ms_per_step": [e["host_ms_per_step"] for e in every if e],
+            "host_blocked_in_readback_ms_per_step": [e["host_blocked_in_readback_ms_per_step"] for e in every if e],
+            "exchange_rank0": ex[0] if ex else None,
+            "exposed_wait_ms_median_over_ranks": round(statistics.median(waits), 3) if waits else None,
+            "exposed_wait_ms_max_over_ranks": round(max(e["exposed_wait_ms_max"] for e in ex if e.get("exposed_wait_ms_max") is not None), 3)
+            if waits else None,
+            "parameter_checksum_max_minus_min": int((hi - lo).item()),
+            "same_step_overlap_off": ab}
+
+
+def synthetic_smiles_frame(n, seed=0):
+    """n SMILES-like strings over 26 regular tokens (so that the vocabularies built from them have the 28 / 30 entries of
+    the synthetic token batches and the benchmarked model can consume them), MOSES-like token counts N(35, 8) in [15, 78]."""
+    import numpy as np
+    import pandas as pd
+    toks = ["C", "c", "N", "O", "n", "(", ")", "1", "2", "=", "F", "S", "o", "s", "3", "#", "Cl", "Br", "[nH]", "-",
+            "4", "[C@H]", "[C@@H]", "/", "[O-]", "[N+]"]
+    rng = np.random.default_rng(seed)
+    lens = np.clip(np.round(rng.normal(35, 8, n)), 15, 78).astype(int)
+    w = 1.0 / np.arange(1, len(toks) + 1)
+    w /= w.sum()
+    rows = []
+    for i in range(n):
+        ids = rng.choice(len(toks), size=lens[i], p=w)
+        if i < len(toks):
+            ids[0] = i                      # every token occurs
+        rows.append("".join(toks[j] for j in ids))
+    return pd.DataFrame({"src": rows, "trg": rows})
+
+
+def trainer_loop_legs(a, inner, opt, state, step, region, fence, reduce_max, make_pool, dev, world, rank, nxt):
+    import logging
+    import tempfile
+    import types
+    from gct_plus_amd import data, synthetic
+    from gct_plus_amd.Train.trainer1 import run_epoch
+    mtype = a.model_type
+    nc = synthetic.n_conds(mtype)
+    tmp = tempfile.mkdtemp(prefix="gct_bench_")
+    LOG = logging.getLogger("gct_bench_trainer")
+    LOG.setLevel(logging.INFO)
+    LOG.propagate = False
+    fh = logging.FileHandler(os.path.join(tmp, "records.log"))     # the reference logs every step to records.log (+ console)
+    fh.setFormatter(logging.Formatter("%(asctime)s - %(name)s - %(levelname)s - %(message)s"))
+    LOG.addHandler(fh)
+    args = types.SimpleNamespace(model_type=mtype, pad_id=synthetic.PAD_ID, use_cond2dec=False,
+                                 property_list=["logP", "tPSA", "QED"][:nc], lr_scheduler="WarmUpDefault",
+                                 lr_WarmUpSteps=8000, d_model=512, print_every=1)
+    model = state.get("dp_model", inner)
+    k = 20
+    res = {"steps": k, "note": "Train.trainer1.run_epoch (loss read-back, records.log line and LR write every step, -print_every "
+                               "1 as the reference's default) over batches staged in HBM vs this file's bare step on the same "
+                               "batches; ratio = bare / trainer (1.0: the loop costs nothing)"}
+
+    def timed_epoch(loader, cur):
+        fence()
+        t0 = time.perf_counter()
+        _, cur = run_epoch(args, model, opt, loader, cur, 0.04, LOG, train=True)
+        fence()
+        return reduce_max(time.perf_counter() - t0), cur
+
+    cur = 100000
+    for B in dict.fromkeys((a.batch, 128, 64)):
+        pool_b = make_pool(False, batch=B)
+        loader = [pool_b[i % len(pool_b)] for i in range(k)]
+        _, cur = run_epoch(args, model, opt, loader[:3], cur, 0.04, LOG, train=True)     # warm-up (shapes, workspaces)
+        dt_t, cur = timed_epoch(loader, cur)
+        state["pool"] = pool_b
+        for i in range(3):
+            step(nxt + i)
+        dt_b, _ = region(nxt + 3, k)
+        nxt += 3 + k
+        res[f"batch_{B}"] = {"trainer_ms_per_step": round(dt_t / k * 1e3, 3), "bare_ms_per_step": round(dt_b / k * 1e3, 3),
+                             "trainer_smiles_per_s": round(B * world * k / dt_t, 1), "ratio": round(dt_b / dt_t, 4)}
+    # behind the loader: native tokenizer + collate per batch (gct_plus_amd.data.SmilesLoader), unconditioned types only
+    # (the conditioned ones need property columns; the loop is the same)
+    if nc == 0 and mtype == "vaetf":
+        B = a.batch
+        frame = synthetic_smiles_frame(B * k * world, seed=3)
+        SRC, TRG, _ = data.get_fields(mtype, os.path.join(tmp, "utils"), frame["src"].tolist())
+        vs, vt = synthetic.vocab_sizes(mtype)
+        if len(SRC) <= vs and len(TRG) <= vt:
+            loader = data.SmilesLoader(frame, SRC, TRG, mtype, [], B, rank, world, shuffle=False, seed=0, device=dev)
+            warm = data.SmilesLoader(frame.iloc[:3 * B * world], SRC, TRG, mtype, [], B, rank, world, shuffle=False, seed=0, device=dev)
+            _, cur = run_epoch(args, model, opt, warm, cur, 0.04, LOG, train=True)
+            dt_l, cur = timed_epoch(loader, cur)
+            res["behind_loader"] = {"batch": B, "steps": len(loader), "ms_per_step": round(dt_l / len(loader) * 1e3, 3),
+                                    "smiles_per_s": round(B * world * len(loader) / dt_l, 1),
+                                    "note": "SMILES strings -> native tokenizer + collate (padded to the batch's longest row, so "
+                                            "batches are shorter than the staged 80-wide ones) -> run_epoch"}
+        else:
+            res["behind_loader"] = {"skipped": f"vocabulary {len(SRC)}/{len(TRG)} larger than the model's {vs}/{vt}"}
+    LOG.removeHandler(fh)
+    fh.close()
+    return res
+
+
 def replay_switch_children(rows=512, budget_s=200.0):
     """Only when graph replay was the slower mode: the decode comparison of tools/graph_probe.py repeated in CHILD
     processes (fresh HIP runtimes; this process only waits) under the runtime switches that change where a graph's
@@ -435,24 +578,37 @@ def worker(a):
     # synthetic MOSES-shaped pool, sharded like DistributedSampler, staged in HBM up front
     S = 20 if (a.tiny or cpu) else 80
 
-    def make_pool(fixed_len):
-        n_pool = 4
-        ds = synthetic.make_dataset(a.batch * n_pool * world, S, mtype, seed=0, fixed_len=fixed_len)
+    def make_pool(fixed_len, batch=None, mt=None):
+        n_pool, batch = 4, batch or a.batch
+        ds = synthetic.make_dataset(batch * n_pool * world, S, mt or mtype, seed=0, fixed_len=fixed_len)
         idx = synthetic.shard_indices(ds["src"].size(0), world, rank, epoch=0, seed=0, shuffle=False)
         shard = {k: v[idx] for k, v in ds.items()}
-        return [{k: v.to(dev) for k, v in b.items()} for b in synthetic.batches(shard, a.batch)]
+        return [{k: v.to(dev) for k, v in b.items()} for b in synthetic.batches(shard, batch)]
 
     pool = make_pool(a.fixed_len)
     state = {"pool": pool}
 
+    state.update(fwd_loss=fwd_loss, opt=opt, dp_model=getattr(fwd_loss, "model", inner))
+
+    host = {"s": 0.0, "n": 0}
+
     def step(i):
+        t_h = time.perf_counter()
+        try:
+            return _step(i)
+        finally:
+            host["s"] += time.perf_counter() - t_h
+            host["n"] += 1
+
+    def _step(i):
         batch = state["pool"][i % len(state["pool"])]
-        loss = fwd_loss(batch)
-        opt.zero_grad(set_to_none=True)
+        loss = state["fwd_loss"](batch)
+        o = state["opt"]
+        o.zero_grad(set_to_none=True)
         loss.backward()
-        opt.step()
+        o.step()
         lr = warmup_lr(i + 1, 512, 8000)
-        for g in opt.param_groups:
+        for g in o.param_groups:
             g["lr"] = lr
         return loss
 
@@ -482,6 +638,13 @@ def worker(a):
     for i in range(a.warmup):
         step(i)
     fence()
+    dpm = state["dp_model"] if world > 1 and hasattr(state.get("dp_model"), "diag_summary") else None
+    if dpm is not None:
+        dpm.diag = True
+        dpm.diag_reset()
+    host.update(s=0.0, n=0)
+    if ops is not None:
+        ops.HOST_BLOCKED_S[0] = 0.0
     if not cpu and not a.no_kernel_timing:
         ops.PROFILE = {}
         # only the roofline kernel is bracketed by events inside the timed region (all three GEMM
@@ -493,6 +656,10 @@ def worker(a):
         prof, ops.PROFILE = ops.PROFILE, None
     final_loss = float(last.item()) / a.batch
     nxt = a.warmup + a.steps
+    multi = None
+    if world > 1:
+        multi = multi_rank_report(a, dpm, inner, host, ops, dev, world, rank, cpu, step, region, nxt)
+        nxt += 8
 
     # the same step on batches WITHOUT padding (every sample 80 tokens): none of the data-dependent
     # shortcuts (zero-gradient query tiles, zero rows of the decoder backward) can apply
@@ -536,6 +703,45 @@ def worker(a):
         alt = {"gemm_arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "steps": k2,
                "ms_per_step": round(dt2 / k2 * 1e3, 3), "value": round(a.batch * world * k2 / dt2, 1)}
 
+    # Train.trainer1.run_epoch itself (per-step loss read-back, log line, LR write -- the reference's loop,
+    # Train/trainer1.py:80-151) over staged batches at this run's batch size and at the reference scripts' 128 and 64
+    # (Bashscript/train/train_vaetf.sh:10-18, train_scavaetf.sh:10-20), against the bare step of this file on the same
+    # batches; and once behind the tokenizer + collate loader on synthetic SMILES strings
+    tloop = None
+    if not cpu and not a.no_trainer_loop and not a.tiny:
+        tloop = trainer_loop_legs(a, inner, opt, state, step, region, fence, reduce_max, make_pool, dev, world, rank, nxt)
+        nxt += 4000
+        state["pool"] = pool
+
+    # the other model types (BASELINE configs[2] = pvaetf, the 1-GPU point of configs[3] = scavaetf, pscavaetf): short legs
+    # on MOSES-like batches and on unpadded ones, same step, same pool logic
+    others = None
+    if not cpu and not a.no_model_types and not a.tiny:
+        others = {}
+        for mt in ("vaetf", "pvaetf", "scavaetf", "pscavaetf"):
+            if mt == mtype:
+                continue
+            m2, o2, f2 = hip_workload(a, dev, world, rank, mtype=mt)
+            state.update(fwd_loss=f2, opt=o2, pool=make_pool(False, mt=mt))
+            for i in range(2):
+                step(nxt + i)
+            dtm, _ = region(nxt + 2, 7)
+            state["pool"] = make_pool(True, mt=mt)
+            for i in range(2):
+                step(nxt + 9 + i)
+            dtf, _ = region(nxt + 11, 5)
+            nxt += 16
+            others[mt] = {"steps": 7, "ms_per_step": round(dtm / 7 * 1e3, 3), "value": round(a.batch * world * 7 / dtm, 1),
+                          "fixed_len_80": {"steps": 5, "ms_per_step": round(dtf / 5 * 1e3, 3),
+                                           "value": round(a.batch * world * 5 / dtf, 1),
+                                           "step_tflops_executed": round(FLOP_PER_SMILES_STEP[mt] * a.batch * world * 5 / dtf / 1e12, 2)}}
+            del m2, o2, f2
+            state.update(fwd_loss=fwd_loss, opt=opt, pool=pool)
+            torch.cuda.empty_cache()
+        others["note"] = (f"batch {a.batch}/GPU, dropout {a.dropout}, 7 timed steps after 2 warm-up on MOSES-like lengths, 5 after 2 "
+                          "on unpadded batches; pvaetf = BASELINE configs[2] (encoder length 83, cross-attention keys 86), "
+                          "scavaetf = the per-GPU point of configs[3]")
+
     dec = None
     if not cpu and not a.no_decode and not a.tiny:
         dec = decode_block(inner, a, dev, world, fence, reduce_max)
@@ -553,9 +759,11 @@ def worker(a):
                               "seq_len": S, "parallelism": f"dp{world}"},
                    "ranks": world, "backend": backend, "launcher": launcher,
                    "final_loss_per_sample": round(final_loss, 4)}
+            if multi is not None:
+                out["multi_rank"] = multi
             print(json.dumps(out), flush=True)
         else:
-            roof = roofline(prof, dt)
+            roof = roofline(prof, dt, a.steps)
             out = {
                 "metric": f"SMILES/sec training step ({mtype}, seq_len=80, d_model=512)",
                 "value": round(value, 1), "unit": "SMILES/s", "n_gpus": world, "steps": a.steps,
@@ -595,6 +803,12 @@ def worker(a):
                 out["step_tflops_executed_fixed_len_80"] = round(FLOP_PER_SMILES_STEP[mtype] * fixed["value"] / 1e12, 2)
             if alt is not None:
                 out["same_step_fp32_mfma_gemms"] = alt
+            if multi is not None:
+                out["multi_rank"] = multi
+            if others is not None:
+                out["model_types"] = others
+            if tloop is not None:
+                out["trainer_loop"] = tloop
             if dec is not None:
                 out["decode"] = dec
             if world == 1 and not a.no_cpu_baseline and not a.tiny:
@@ -605,7 +819,7 @@ def worker(a):
         dist.destroy_process_group()
 
 
-def roofline(prof, dt):
+def roofline(prof, dt, steps=0):
     """`roofline` object for the dominant kernel from the live HIP-event brackets of ops._Timed."""
     if not prof:
         return None
@@ -633,6 +847,23 @@ def roofline(prof, dt):
         rec = json.load(open(cands[-1]))
         traffic = rec.get("hbm_bytes_per_launch")
         tsrc = {"file": os.path.relpath(cands[-1], ROOT), "commit": rec.get("commit", "unrecorded (round 1)")}
+    # algorithmic bytes of THIS run's forward-GEMM calls (operands read once, results written once) against what the
+    # counters saw for the forward GEMM kernels of a step (every launch of the 128 x 256-tile and the 64 x 128-tile
+    # forward kernels, from the same committed summary): > 1 = re-reads (operand panels fetched by more than one XCD's L2)
+    alg = prof.get("_bytes:" + dom)
+    ncalls = len(prof[dom]) if dom in prof else 0
+    nl = klaunch.get(dom) or ncalls
+    alg_per_launch = round(alg / nl) if (alg and nl) else None
+    ratio, per_step = None, None
+    if cands and alg and ncalls and steps:
+        allk = rec.get("all", {})
+        psteps = (allk.get("adam_kernel") or {}).get("launches") or rec.get("steps_profiled")
+        fw = [v for k, v in allk.items() if k.startswith("gemm_x6_kernel<0>") or k.startswith("gemm_x6s_kernel<0>")
+              or (not x6 and k.startswith("gemm_f32_fast_kernel"))]
+        if psteps and fw:
+            per_step = {"counters_bytes": round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in fw) / psteps),
+                        "algorithmic_bytes": round(alg / steps)}
+            ratio = round(per_step["counters_bytes"] / per_step["algorithmic_bytes"], 3)
     if x6:
         # bf16 MFMA pipe, six bf16 partial products per fp32 product: the fp32-equivalent
         # ceiling of the kernel is the dense bf16 peak / 6
@@ -642,7 +873,8 @@ def roofline(prof, dt):
                 "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / peak, 4),
                 "mfma_utilisation": round(6 * kern[dom]["tflops"] / PEAK_BF16_MFMA_TFLOPS, 4),
-                "traffic": traffic, "traffic_source": tsrc,
+                "traffic": traffic, "traffic_algorithmic": alg_per_launch, "traffic_ratio": ratio,
+                "traffic_forward_gemms_per_step": per_step, "traffic_source": tsrc,
                 "traffic_source_commit": tsrc["commit"] if tsrc else None,
                 "avg_launch_us": kern[dom].get("avg_kernel_us", kern[dom]["avg_us"]),
                 "launches": kern[dom].get("kernel_launches", kern[dom]["launches"]),
@@ -658,7 +890,8 @@ def roofline(prof, dt):
     return {"kernel": "gemm_f32_fast_kernel<true,true> (nn.Linear forward, every shape of the step)",
             "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": traffic, "traffic_source": tsrc, "traffic_source_commit": tsrc["commit"] if tsrc else None,
+            "traffic": traffic, "traffic_algorithmic": alg_per_launch, "traffic_ratio": ratio,
+            "traffic_forward_gemms_per_step": per_step, "traffic_source": tsrc, "traffic_source_commit": tsrc["commit"] if tsrc else None,
             "avg_launch_us": kern[dom]["avg_us"], "launches": kern[dom]["launches"], "kernels": kern}
 
 

@@ -43,6 +43,15 @@ class FlatDataParallel(nn.Module):
         self._ar_fn, self._bc_fn = allreduce, broadcast
         self._flat_ok = getattr(module, "_gct_flat", None) is not None
         self._armed = False
+        self._in_finalize = False
+        # Diagnostics for a first run on real multi-GPU hardware (bench.py prints them at N > 1): per backward pass
+        # how many buckets / bytes were exchanged from INSIDE the backward (overlapped) and how many from the
+        # end-of-backward callback (exposed), and how long the compute stream sat waiting for the exchange there
+        # (device time between two events around the waits; host time on CPU rigs).  Off unless `diag` is set.
+        self.diag = False
+        self.stats = {"backward_passes": 0, "buckets_in_backward": 0, "bytes_in_backward": 0,
+                      "buckets_at_finalize": 0, "bytes_at_finalize": 0, "exposed_wait_ms": []}
+        self._wait_events = []
         self._nccl = dist.get_backend(process_group) == "nccl" and allreduce is None
         self._avg_native = self._nccl
         if self._nccl:
@@ -119,7 +128,7 @@ class FlatDataParallel(nn.Module):
                       for g in self._buckets]
 
     def _on_grad(self, p):
-        if not self._armed or id(p) in self._fired:
+        if not self._armed or not self.overlap or id(p) in self._fired:      # overlap off: everything from _finalize
             return
         self._fired.add(id(p))
         bi = self._bucket_of[id(p)]
@@ -133,16 +142,22 @@ class FlatDataParallel(nn.Module):
         waits for the end of the backward pass like before)."""
         if not self._armed or not self.overlap:
             return
+        ready = []
         for p, gt in zip(params, grads):
             bi = self._bucket_of.get(id(p))
-            if bi is None or not p.requires_grad:
+            if bi is None or not p.requires_grad or id(p) in self._dead:
+                continue                               # (dead parameters are not counted in _left either)
+            if gt is None:
+                # the trunk produced no gradient for it: on the first backward that is how the dead set is learned
+                # (not fired), afterwards its bucket simply waits for _finalize
+                self._late[bi] = True
                 continue
             v = getattr(p, "_gct_gview", None)
-            if gt is None or v is None or gt.data_ptr() != v.data_ptr():
+            if v is None or gt.data_ptr() != v.data_ptr():
                 self._late[bi] = True                  # not in its slot: exchanged from _finalize
-        for p in params:
-            if id(p) in self._bucket_of:
-                self._on_grad(p)
+            ready.append(p)
+        for p in ready:
+            self._on_grad(p)
 
     @torch.no_grad()
     def _launch(self, bi):
@@ -159,9 +174,18 @@ class FlatDataParallel(nn.Module):
         t = self.module.flat_grads()[g["start"]:g["end"]]
         self._works.append((self._allreduce(t), t))
         self._launched[bi] = True
+        if self.diag:
+            k = "at_finalize" if self._in_finalize else "in_backward"
+            self.stats["buckets_" + k] += 1
+            self.stats["bytes_" + k] += t.numel() * 4
 
     # ------------------------------------------------------------------------- forward/hooks
     def forward(self, *args, **kwargs):
+        if self._armed:
+            # a backward pass that raised before its end-of-backward callback left the wrapper armed (and the engine's
+            # notifier pointing here): start this pass clean
+            self._armed = False
+            self._disarm_notifier()
         out = self.module(*args, **kwargs)
         if torch.is_grad_enabled():
             anchor = next((o for o in (out if isinstance(out, (tuple, list)) else (out,))
@@ -182,14 +206,24 @@ class FlatDataParallel(nn.Module):
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
         return grad
 
-    @torch.no_grad()
-    def _finalize(self):
-        self._armed = False
-        m = self.module
+    def _disarm_notifier(self):
         if self._flat_ok:
             from . import engine
             if engine.GRAD_NOTIFY == self._notify:
                 engine.GRAD_NOTIFY = None
+
+    @torch.no_grad()
+    def _finalize(self):
+        self._armed = False
+        m = self.module
+        self._disarm_notifier()
+        self._in_finalize = True
+        try:
+            self._finalize_body(m)
+        finally:
+            self._in_finalize = False
+
+    def _finalize_body(self, m):
         if self._flat_ok:
             if not self._learned:                      # first backward: learn the dead set
                 self._dead = {id(p) for g in self._buckets for p in g["params"]
@@ -198,10 +232,25 @@ class FlatDataParallel(nn.Module):
             for bi in range(len(self._buckets)):
                 if not self._launched[bi]:
                     self._launch(bi)
+            cuda = self.diag and self._works and self._works[0][1].is_cuda
+            if self.diag:
+                import time
+                self.stats["backward_passes"] += 1
+                if cuda:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                else:
+                    t0 = time.perf_counter()
             for w, t in self._works:
                 w.wait()
                 if not self._avg_native:
                     t.mul_(1.0 / self.world)
+            if self.diag:
+                if cuda:
+                    e1.record()                         # resolved later (diag_summary): no synchronisation here
+                    self._wait_events.append((e0, e1))
+                else:
+                    self.stats["exposed_wait_ms"].append((time.perf_counter() - t0) * 1e3)
             self._works = []
         else:
             for p in m.parameters():
@@ -210,6 +259,30 @@ class FlatDataParallel(nn.Module):
                 self._allreduce(p.grad).wait()
                 if not self._avg_native:
                     p.grad.mul_(1.0 / self.world)
+
+    def diag_reset(self):
+        self.stats = {"backward_passes": 0, "buckets_in_backward": 0, "bytes_in_backward": 0,
+                      "buckets_at_finalize": 0, "bytes_at_finalize": 0, "exposed_wait_ms": []}
+        self._wait_events = []
+
+    def diag_summary(self):
+        """Per-backward-pass averages of the counters + the exposed wait (ms: median and max over the passes).  Resolves
+        the pending event pairs, so call it after the timed region (it synchronises on them)."""
+        import statistics
+        for e0, e1 in self._wait_events:
+            e1.synchronize()
+            self.stats["exposed_wait_ms"].append(e0.elapsed_time(e1))
+        self._wait_events = []
+        n = max(self.stats["backward_passes"], 1)
+        w = self.stats["exposed_wait_ms"]
+        return {"backward_passes": self.stats["backward_passes"], "buckets": len(self._buckets),
+                "buckets_in_backward_per_pass": round(self.stats["buckets_in_backward"] / n, 2),
+                "mb_in_backward_per_pass": round(self.stats["bytes_in_backward"] / n / 1e6, 2),
+                "buckets_at_finalize_per_pass": round(self.stats["buckets_at_finalize"] / n, 2),
+                "mb_at_finalize_per_pass": round(self.stats["bytes_at_finalize"] / n / 1e6, 2),
+                "exposed_wait_ms_median": round(statistics.median(w), 3) if w else None,
+                "exposed_wait_ms_max": round(max(w), 3) if w else None,
+                "overlap": bool(self.overlap), "avg_native": bool(self._avg_native)}
 
     def _allreduce(self, t):
         if self._ar_fn is not None:

@@ -47,6 +47,10 @@ GRAD_NOTIFY = None
 
 def _grads_done(module, G: "GradSink"):
     if GRAD_NOTIFY is not None:
+        # with GCT_SIDE_STREAM=1 the layer's weight gradients were written on the side stream: the exchange that the
+        # notifier may launch is ordered behind the CURRENT stream only, so the side stream joins first
+        if ops.SIDE_ENABLED:
+            ops.join_side()
         ps = list(module.parameters())
         GRAD_NOTIFY(ps, [G.out.get(p) for p in ps])
 

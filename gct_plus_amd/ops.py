@@ -187,8 +187,8 @@ PROFILE_KINDS = None      # None: every GEMM kind; else a set such as {"gemm_fwd
 
 
 class _Timed:
-    def __init__(self, kind, flops):
-        self.kind, self.flops = kind, flops
+    def __init__(self, kind, flops, nbytes=0):
+        self.kind, self.flops, self.nbytes = kind, flops, nbytes
 
     def __enter__(self):
         self.on = PROFILE is not None and (PROFILE_KINDS is None or self.kind in PROFILE_KINDS)
@@ -208,6 +208,8 @@ class _Timed:
             PROFILE.setdefault(kind, []).append((self.flops, self.e0, self.e1))
             PROFILE["_x6_kernel_launches:" + kind] = PROFILE.get("_x6_kernel_launches:" + kind, 0) + \
                 (_L().gct_gemm_x6_kernel_launches() - self.k0)
+            # algorithmic HBM bytes of the calls (every operand read once, every result written once)
+            PROFILE["_bytes:" + kind] = PROFILE.get("_bytes:" + kind, 0) + self.nbytes
 
 
 def _seg3(ts: Sequence[Optional[torch.Tensor]]):
@@ -308,7 +310,9 @@ def linear_fwd(x2d, ws_: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Ten
         return
     wp, pstride = _plane_ptr(ws_)
     wsb = ws if ws is not None else (workspace(need, x2d.device) if need > 256 else None)
-    with _Timed("gemm_fwd", 2.0 * M * K * nper * len(ws_)):
+    N = nper * len(ws_)
+    nbytes = 4 * M * K + (6 if wp else 4) * N * K + 4 * N + 4 * M * N * (2 if epi in (EPI_GELU_DROP, EPI_DROP_RESID) else 1)
+    with _Timed("gemm_fwd", 2.0 * M * K * N, nbytes):
         check(_L().gct_linear_fwd_p(_p(x2d), x2d.stride(0), M, K, w[0], w[1], w[2], ws_[0].stride(0),
                                     wp, pstride, b[0], b[1], b[2], len(ws_), nper, y[0], y[1], y[2],
                                     ldy, epi, _p(resid), _p(pre), p, seed, site, _p(wsb),
@@ -463,12 +467,18 @@ class LiveRows:
         return dst
 
 
+HOST_BLOCKED_S = [0.0]      # host seconds spent waiting in read_back (the one synchronisation of a training step)
+
+
 def read_back(*objs):
     """host() of several LiveRows / KeyRows with ONE device->host copy (one synchronisation instead of one each)."""
     objs = [o for o in objs if o is not None and o._host is None]
     if not objs:
         return
+    import time
+    t0 = time.perf_counter()
     v = torch.cat([o.info for o in objs] + [skipped_row_gradients()]).tolist()
+    HOST_BLOCKED_S[0] += time.perf_counter() - t0
     for i, o in enumerate(objs):
         o._fill_host(v[8 * i:8 * i + 8])
     if v[-1] != 0:

@@ -34,6 +34,18 @@ def test_plain_gpus2_spawns_two_ranks_cpu(mtype):
     assert out["scaling"] == "weak" and out["ms_per_step"] > 0
     assert abs(out["value"] - 16 * 4 / (out["ms_per_step"] * 4e-3)) / out["value"] < 1e-2
     assert "self-test" in out["metric"]              # can never be mistaken for a benchmark line
+    # the multi-rank report of the line (what a first run on real GPUs is read by): both ranks seen and named,
+    # the gradient exchange counted per backward pass, parameters bit-identical across ranks, the overlap-off A/B leg
+    mr = out["multi_rank"]
+    assert mr["ranks_seen"] == 2 and [i["rank"] for i in mr["identities"]] == [0, 1]
+    assert len({i["pid"] for i in mr["identities"]}) == 2
+    assert mr["parameter_checksum_max_minus_min"] == 0
+    ex = mr["exchange_rank0"]
+    assert ex["backward_passes"] == 4 and ex["buckets"] >= 1
+    assert abs(ex["buckets_in_backward_per_pass"] + ex["buckets_at_finalize_per_pass"] - ex["buckets"]) < 1e-6
+    assert ex["exposed_wait_ms_median"] is not None and mr["exposed_wait_ms_max_over_ranks"] >= 0
+    assert len(mr["host_ms_per_step"]) == 2 and all(h > 0 for h in mr["host_ms_per_step"])
+    assert mr["same_step_overlap_off"]["ms_per_step"] > 0
 
 
 def test_single_rank_cpu_selftest_and_world_mismatch():
@@ -63,6 +75,11 @@ def test_plain_gpus2_real_model_shared_gpu():
     assert out["roofline"] is None or "kernel" in out["roofline"]
     assert out["fixed_len_80"]["ms_per_step"] > 0
     assert out["final_loss_per_sample"] == out["final_loss_per_sample"]      # not NaN
+    mr = out["multi_rank"]
+    assert mr["ranks_seen"] == 2 and mr["parameter_checksum_max_minus_min"] == 0
+    ex = mr["exchange_rank0"]
+    # per-layer buckets leave from inside the trunk backward once the dead set is known (after the first pass)
+    assert ex["buckets_in_backward_per_pass"] > 0 and ex["exposed_wait_ms_median"] is not None
 
 
 def test_replay_switch_children_never_raise():

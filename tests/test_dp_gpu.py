@@ -46,11 +46,12 @@ def _build(seed):
     return model_dict["pvaetf"](28, 30, dropout=0.0, nconds=3, use_cond2lat=True, **KW).cuda().train()
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, side=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from gct_plus_amd import synthetic
+    from gct_plus_amd import ops, synthetic
+    ops.SIDE_ENABLED = bool(side)                 # weight gradients on the side stream (GCT_SIDE_STREAM=1)
     from gct_plus_amd.dp import FlatDataParallel
     from gct_plus_amd.optim import FusedAdam
     from gct_plus_amd.testing import host_staged_allreduce, host_staged_broadcast
@@ -70,11 +71,15 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_process_global_batch():
+@pytest.mark.parametrize("side", [False, True])
+def test_two_ranks_match_single_process_global_batch(side):
+    """side=True: the weight gradients are written on the side stream while the per-layer buckets leave from inside the
+    trunk backward (engine._grads_done joins the side stream before it notifies; without that join a bucket could be
+    exchanged before its gradients had landed -- round-3 advisor finding)."""
     world, port = 2, _port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, side), nprocs=world, join=True)
     a, b = out[0], out[1]
     for k in a:
         assert torch.equal(a[k], b[k]), f"ranks diverged on {k}"

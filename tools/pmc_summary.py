@@ -19,7 +19,11 @@ import os
 import re
 
 SHORT = [(r"gemm_x6_kernel<0>", "gemm_x6_kernel<0> (forward)"), (r"gemm_x6_kernel<1>", "gemm_x6_kernel<1> (dgrad)"),
-         (r"gemm_x6_kernel<2>", "gemm_x6_kernel<2> (wgrad)"), (r"attn_fwd_kernel<4", "attn_fwd_kernel<4,..>"),
+         (r"gemm_x6_kernel<2>", "gemm_x6_kernel<2> (wgrad)"),
+         (r"gemm_x6s_kernel<0>", "gemm_x6s_kernel<0> (forward, 64x128 tiles)"),
+         (r"gemm_x6s_kernel<1>", "gemm_x6s_kernel<1> (dgrad, 64x128 tiles)"),
+         (r"splitk_epilogue_kernel", "splitk_epilogue_kernel"), (r"reduce_slabs2_kernel", "reduce_slabs2_kernel"),
+         (r"attn_fwd_kernel<4", "attn_fwd_kernel<4,..>"),
          (r"attn_bwd_kernel<4", "attn_bwd_kernel<4,..>"), (r"attn_fwd_direct_kernel<4", "attn_fwd_direct_kernel<4,6>"),
          (r"attn_bwd_dq_kernel<4", "attn_bwd_dq_kernel<4,6>"), (r"attn_bwd_dkv_kernel<4", "attn_bwd_dkv_kernel<4,6>"),
          (r"norm_fwd_kernel", "norm_fwd_kernel"),
@@ -84,6 +88,8 @@ def main():
             "correction": "hbm = (2*FETCH_SIZE + WRITE_SIZE)*1024 B (gfx950: FETCH_SIZE counts 128-B requests at 64 B)"}
     if a.out_traffic and traffic:
         out = dict(head, kernel="gemm_x6_kernel<0> (nn.Linear forward, bf16x6)", all=traffic)
+        if "adam_kernel" in traffic:
+            out["steps_profiled"] = traffic["adam_kernel"]["launches"]          # one Adam launch per training step
         if "gemm_x6_kernel<0> (forward)" in traffic:
             out["hbm_bytes_per_launch"] = traffic["gemm_x6_kernel<0> (forward)"]["hbm_bytes_per_launch"]
         json.dump(out, open(a.out_traffic, "w"), indent=1)
