@@ -78,7 +78,8 @@ class Decoder(nn.Module, _TrunkParams):
 
     def forward(self, trg, z, src_mask, trg_mask, dconds, loss_rows=None, _compact_out=False, _plan=None):
         """loss_rows (bool / uint8 [B, T], optional -- an extension of this build): the rows whose output reaches the
-        loss; the others are not computed and come back as zeros (engine.decoder_trunk_fwd)."""
+        loss; the others are not computed: they come back as zeros, except the (at most 3 per sample) padded rows that
+        share an aligned group of four rows with a live one, which hold arbitrary finite values (engine.decoder_trunk_fwd)."""
         run = engine.Run(self.p, self.training)
         if loss_rows is not None:
             loss_rows = loss_rows.to(torch.uint8).contiguous()
@@ -162,7 +163,8 @@ class Vaetf(FlatModelMixin, nn.Module):
     def forward(self, src, trg, src_mask, trg_mask, econds=None, dconds=None, *, loss_rows=None):
         """Reference signature (Model/vaetf.py:154) plus one keyword-only extension: loss_rows (bool [B, T]) names the
         decoder rows whose logits reach the loss -- the trainer passes `ys != pad` (Model/forward_propagation1.py); the
-        other rows are then not computed at all and their logits come back as zeros, NOT as the reference's values.  Default (None): every row, as the reference."""
+        other rows are then not computed at all: their logits come back as zeros -- or, for the few padded rows that share an
+        aligned group of four with a live row, as arbitrary finite values -- NOT as the reference's values.  Default (None): every row, as the reference."""
         if self.get_attn or (self.use_cond2dec and self.nconds > 0):
             loss_rows = None
         plan = _row_plan(self, src_mask, trg_mask, loss_rows, trg)

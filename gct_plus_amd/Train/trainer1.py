@@ -97,6 +97,9 @@ def run_epoch(args, model, optimizer, dataloader, current_step, beta, LOG, train
                      f'KLD: {history["KLD"][-1]:.5f}\tLOSS: {history["LOSS"][-1]:.5f}\t'
                      f'TIME(s): {time() + cost_time:.1f}\tMODELTIME(s): {model_cost_time:.1f}\t'
                      f'UPDATETIME(s): {update_cost_time:.1f}')
+    if train and next(model.parameters()).is_cuda:
+        from .. import ops
+        ops.assert_no_skipped_row_gradients()     # (every earlier step's counter was read with the next step's row plan)
     if train:
         return history, current_step
     return history

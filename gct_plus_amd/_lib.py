@@ -75,17 +75,15 @@ SIGNATURES = {
     "gct_smiles_tokenize": (I32, [C.c_char_p, I32, P, P, I32]),
     "gct_smiles_encode_batch": (I32, [P, I32, I32, P, I32, I64, I64, I64, I64, P, I64, P]),
     "gct_adam_step": (I32, [P, P, P, P, I64, F32, F32, F32, F32, I64, F32, P]),
+    "gct_adam_step_guarded": (I32, [P, P, P, P, I64, F32, F32, F32, F32, I64, F32, P, P]),
     "gct_copy_rows": (I32, [P, I64, I64, P, I64, I64, I64, I64, I32, I32, P]),
     "gct_small_linear_fwd": (I32, [P, P, P, P, I32, I32, I32, P]),
     "gct_small_linear_bwd": (I32, [P, P, P, P, I32, I32, I32, P]),
     "gct_reduce_slabs": (I32, [P, I32, I64, P, I64, I32, P]),
     "gct_add": (I32, [P, P, P, I64, P]),
-    "gct_graph_probe": (I32, [I32, I32, I32, P, P, P]),
-    "gct_device_facts": (I32, [C.c_char_p, I32]),
-    "gct_graph_census": (I32, [P, P]),
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 _lib = None
 
 
@@ -114,6 +112,38 @@ def load():
         raise GctError(f"ABI mismatch: library {lib.gct_version()} != binding {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+# ---- the diagnostics library (include/gctplus_diag.h): separate from the operator boundary, optional at run time
+DIAG_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgctplus_diag.so")
+DIAG_SIGNATURES = {
+    "gct_diag_last_error": (C.c_char_p, []),
+    "gct_graph_probe": (I32, [I32, I32, I32, P, P, P]),
+    "gct_device_facts": (I32, [C.c_char_p, I32]),
+    "gct_graph_census": (I32, [P, P]),
+}
+_diag = None
+
+
+def load_diag():
+    """ctypes handle of libgctplus_diag.so (GctError if it is not built: callers treat that as "no diagnosis")."""
+    global _diag
+    if _diag is not None:
+        return _diag
+    if not os.path.exists(DIAG_PATH):
+        raise GctError(f"{DIAG_PATH} is missing (make -C gct_plus_amd/csrc)")
+    lib = C.CDLL(DIAG_PATH)
+    for name, (res, args) in DIAG_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _diag = lib
+    return lib
+
+
+def check_diag(rc: int, what: str):
+    if rc != 0:
+        raise GctError(f"{what} failed (rc={rc}): {load_diag().gct_diag_last_error().decode('utf-8', 'replace')}")
 
 
 _TRACE = os.environ.get("GCT_TRACE_OPS", "0") != "0"    # debugging aid: name every launch on stderr and drain the device

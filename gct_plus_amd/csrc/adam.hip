@@ -12,7 +12,8 @@ namespace {
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v,
                                                    int64_t n4, int64_t n, float b1, float b2,
                                                    float eps, float step_size, float inv_bc2_sqrt,
-                                                   float gscale) {
+                                                   float gscale, const int32_t* __restrict__ skip_if_nonzero) {
+  if (skip_if_nonzero && *skip_if_nonzero != 0) return;     // a gradient landed where none may (see the header)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t e = i * 4;
@@ -45,9 +46,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
 }
 }  // namespace
 
-extern "C" int gct_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
-                             float b1, float b2, float eps, int64_t step, float gscale,
-                             void* stream) {
+extern "C" int gct_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                                     float b1, float b2, float eps, int64_t step, float gscale,
+                                     const int32_t* skip_if_nonzero, void* stream) {
   GCT_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "adam_step: bad args");
   GCT_CHECK_ARG(gct_aligned16(p) && gct_aligned16(g) && gct_aligned16(m) && gct_aligned16(v),
                 "adam_step: buffers must be 16-B aligned");
@@ -60,7 +61,13 @@ extern "C" int gct_adam_step(float* p, const float* g, float* m, float* v, int64
   int64_t grid = (n4 + 255) / 256;
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m,
-                     v, n4, n, b1, b2, eps, step_size, inv_bc2_sqrt, gscale);
+                     v, n4, n, b1, b2, eps, step_size, inv_bc2_sqrt, gscale, skip_if_nonzero);
   GCT_LAUNCH_CHECK("adam_step");
   return GCT_OK;
+}
+
+extern "C" int gct_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                             float b1, float b2, float eps, int64_t step, float gscale,
+                             void* stream) {
+  return gct_adam_step_guarded(p, g, m, v, n, lr, b1, b2, eps, step, gscale, nullptr, stream);
 }

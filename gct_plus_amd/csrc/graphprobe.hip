@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "../../include/gctplus_diag.h"
 
 namespace {
 

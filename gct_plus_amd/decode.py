@@ -63,9 +63,15 @@ class KVDecoder:
 
     # -------------------------------------------------------------------------------------
     @torch.no_grad()
-    def start(self, z, src_mask, dconds=None, max_total_len=208):
+    def start(self, z, src_mask, dconds=None, max_total_len=208, refold=False):
         """z [n, L_e, latent]; src_mask bool [n,1,L_e] (as the reference builds it); max_total_len = longest
-        token sequence (prefix + generated) this call may reach."""
+        token sequence (prefix + generated) this call may reach.
+        refold=True recomputes the folded cross-attention projections even if `model.weights_token()` has not changed:
+        the token follows torch in-place operations on the parameters / the flat buffer and FusedAdam's kernel, but NOT
+        writes through `p.data` (p.data.copy_ / mul_: a separate version counter) or raw kernels of the caller's own --
+        such writers call model.invalidate_weight_planes() (which bumps the token) or pass refold=True here."""
+        if refold:
+            self._fold_key = None
         dec, d = self.dec, self.d
         dev = z.device
         n, Le, lat = z.shape
@@ -433,9 +439,13 @@ class KVDecoder:
         t_graph = min(timed(g.replay), timed(g.replay))
         t_eager = min(timed(eager), timed(eager))
         torch.cuda.synchronize()
-        from . import graphdiag
+        try:                                   # the census is evidence for a report, never a reason to fail a decode
+            from . import graphdiag
+            cen = graphdiag.census(g)
+        except Exception as exc:               # noqa: BLE001 -- diagnostics library missing / hipGraphGetNodes refused
+            cen = {"error": repr(exc)}
         self.replay_probe = {"ms_per_step_graph": round(t_graph, 4), "ms_per_step_eager": round(t_eager, 4),
-                             "steps_timed": k, "rows": self.n, "census": graphdiag.census(g)}
+                             "steps_timed": k, "rows": self.n, "census": cen}
         if t_graph <= REPLAY_SLOW_FACTOR * t_eager:
             return True
         import warnings

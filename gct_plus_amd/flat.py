@@ -106,7 +106,10 @@ class FlatModelMixin:
         to -- a parameter (p.mul_, load_state_dict's copy_: the parameter's own counter, `p.data = view` does not share
         the buffer's) or the flat buffer itself (the data-parallel broadcast); the one writer that goes behind torch's
         back -- FusedAdam's kernel -- reports through invalidate_weight_planes(), which bumps the epoch.  Caches of
-        anything derived from the weights alone (decode.KVDecoder's folded cross-attention projections) key on it."""
+        anything derived from the weights alone (decode.KVDecoder's folded cross-attention projections) key on it.
+        NOT seen: writes through `p.data` (p.data.copy_, p.data.mul_ -- EMA or manual weight surgery: `.data` carries its
+        own version counter) and raw kernels of the caller's own.  Such a writer calls invalidate_weight_planes() after
+        writing (it bumps the epoch) -- or decodes with KVDecoder.start(..., refold=True)."""
         f = self._gct_flat
         if f is None:
             return None

@@ -1,4 +1,5 @@
-"""What this box does with hipGraph replay (csrc/graphprobe.hip): facts, micro-probes and the census of a captured
+"""What this box does with hipGraph replay (libgctplus_diag.so = csrc/graphprobe.hip, include/gctplus_diag.h -- a
+diagnostics library beside the operator library, not part of its ABI): facts, micro-probes and the census of a captured
 graph.  Used by KVDecoder's replay guard, bench.py's decode block and tools/graph_probe.py.
 
 Why it exists: BASELINE configs[4] asks for a hipGraph-captured decode step (reference loop:
@@ -13,7 +14,7 @@ import glob
 import json
 import os
 
-from ._lib import check, load
+from ._lib import check_diag as check, load_diag as load
 
 VARIANTS = {0: "tiny kernel, 8-byte kernarg, 1 workgroup",
             1: "320-byte by-value kernarg read by every wave, 2048 x 512 threads",

@@ -356,9 +356,20 @@ def nonzero_row_tiles(x2d: torch.Tensor):
 
 _SKIPPED = {}
 _SKIPPED_MSG = ("{} decoder rows that an earlier forward skipped (loss_rows: rows that do not reach the loss) received a "
-                "non-zero gradient in its backward pass: that gradient was ignored.  Call the model without loss_rows "
+                "non-zero gradient in its backward pass: that gradient was ignored, and the optimizer steps launched since "
+                "then were skipped on the device (FusedAdam's guard), so no wrong update has been applied; this error is "
+                "raised at the first host read-back after the fact.  Call the model without loss_rows "
                 "(forward_propagation(..., skip_ignored=False)) for losses other than the reference's ignore_index "
                 "cross-entropy.")
+
+
+def assert_no_skipped_row_gradients():
+    """Read the counter now (one synchronisation) and raise if it is non-zero: the trainer calls this at the end of an
+    epoch so that a gradient on a skipped row in the LAST step of a run is reported too."""
+    n = int(skipped_row_gradients().item())
+    if n:
+        skipped_row_gradients().zero_()
+        raise _lib.GctError(_SKIPPED_MSG.format(n))
 
 
 def skipped_row_gradients():
@@ -745,9 +756,11 @@ def ce_bwd(logits2d, target, gout, pad_id):
 
 
 # ------------------------------------------------------------------------------- optimiser
-def adam_step(p, g, m, v, lr, b1, b2, eps, step, gscale=1.0):
-    check(_L().gct_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, step, gscale,
-                             _st()), "gct_adam_step")
+def adam_step(p, g, m, v, lr, b1, b2, eps, step, gscale=1.0, guard=True):
+    """guard: the update is skipped ON THE DEVICE when a gradient has landed on a decoder row that the forward skipped
+    (skipped_row_gradients() != 0): the wrong gradient is never applied, and the next read-back raises."""
+    check(_L().gct_adam_step_guarded(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, step, gscale,
+                                     _p(skipped_row_gradients()) if guard else None, _st()), "gct_adam_step_guarded")
 
 
 # ---------------------------------------------------------------------------------- utility

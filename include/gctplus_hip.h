@@ -37,7 +37,7 @@ extern "C" {
 #define GCT_ERR_ARG (-1)  /* bad shape / alignment / null pointer            */
 #define GCT_ERR_HIP (-2)  /* a HIP runtime call failed (launch error)        */
 
-#define GCT_ABI_VERSION 11
+#define GCT_ABI_VERSION 12
 
 int gct_version(void);
 const char* gct_last_error(void);
@@ -337,6 +337,13 @@ int gct_ce_bwd(const float* logits, const int64_t* target, const float* gout, fl
  * data-parallel mean). `step` is t (1-based, already incremented). */
 int gct_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
                   float b2, float eps, int64_t step, float gscale, void* stream);
+/* The same step behind a device-side guard: when *skip_if_nonzero != 0 at launch time nothing is updated (p, m, v stay
+ * as they are).  The trainer passes the device counter of "gradient rows that fell on decoder rows the forward had
+ * skipped" (gct_live_rows / gct_scatter_add_quads_check): a wrong gradient is then never applied, without a host
+ * synchronisation in front of the update; the host raises at its next read-back.  skip_if_nonzero == NULL: no guard. */
+int gct_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                          float b2, float eps, int64_t step, float gscale, const int32_t* skip_if_nonzero,
+                          void* stream);
 
 /* --------------------------------------------------------- K11: KV-cached decode */
 /* Inference/sampling_tool.py:140-184 re-runs the whole decoder on ys[:, :i+1] each step; these
@@ -412,21 +419,6 @@ int gct_reduce_slabs(const float* slabs, int nslab, int64_t stride, float* dst, 
                      int accumulate, void* stream);
 /* y = a + b (gradient joins of the residual stream) */
 int gct_add(const float* a, const float* b, float* y, int64_t n, void* stream);
-
-/* ------------------------------------------------------------------ hipGraph replay diagnostics (csrc/graphprobe.hip)
- * BASELINE configs[4] asks for a hipGraph-captured decode step (reference loop: Inference/sampling_tool.py:140-184).
- * Some boxes replay graphs far slower than they launch the same kernels one by one; these calls tell a caller what
- * the box does before it trusts a replay.
- * gct_graph_probe: `nodes` launches of a do-nothing kernel chained on a private stream, timed as `reps` eager passes
- *   and as `reps` replays of the captured chain (ms per pass).  variant 0: 8-byte kernarg, one workgroup; 1: a 320-byte
- *   by-value argument block read by every wave of a 2048 x 512 grid; 2: as 1 with 144 KB of dynamic LDS; 3: as 1 with
- *   the block behind one pointer into device memory.  Synchronises its own stream only.
- * gct_device_facts: runtime / driver version, large-BAR and host-access attributes ... as one JSON object.
- * gct_graph_census: node counts of a captured hipGraph_t; out8 = {nodes, kernels, memcpys, memsets, others,
- *   max dynamic LDS bytes, max grid blocks, kernels with more than 64 KB of LDS}. */
-int gct_graph_probe(int variant, int nodes, int reps, float* eager_ms, float* graph_ms, int32_t* graph_nodes);
-int gct_device_facts(char* buf, int cap);
-int gct_graph_census(void* hip_graph, int64_t* out8);
 
 #ifdef __cplusplus
 }

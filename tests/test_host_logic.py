@@ -24,6 +24,13 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.gct_version() == _lib.ABI_VERSION
     assert lib.gct_wgrad_ws_bytes(40960, 512, 512) > 0
+    # the diagnostics library has its own header and is NOT part of the operator ABI
+    dh = open(os.path.join(ROOT, "include", "gctplus_diag.h")).read()
+    ddecl = set(re.findall(r"\b(gct_[a-z0-9_]+)\s*\(", dh))
+    assert ddecl == set(_lib.DIAG_SIGNATURES) and not (ddecl & declared), (ddecl, declared & ddecl)
+    dl = _lib.load_diag()
+    for name in ddecl:
+        assert hasattr(dl, name), name
 
 
 def test_ops_refuse_cpu_tensors():

@@ -718,11 +718,24 @@ def test_gradient_on_a_skipped_row_is_reported(monkeypatch):
     ops.skipped_row_gradients().zero_()
     mol, _ = _fwd_loss_skip(model, mtype, ds, 0.04, True)
     mol.sum().backward()                                  # a loss that reads EVERY row, unlike the ignore_index CE
+    # the optimizer step that follows must NOT apply that gradient: FusedAdam's launch is guarded by the device counter
+    from gct_plus_amd.optim import FusedAdam
+    opt = FusedAdam(model.parameters(), lr=1e-2, betas=(0.9, 0.98), eps=1e-9, model=model)
+    before = model.flat_params().clone()
+    opt.step()
+    assert torch.equal(model.flat_params(), before), "a gradient on skipped rows was applied"
+    with pytest.raises(_lib.GctError, match="skipped"):
+        ops.assert_no_skipped_row_gradients()             # what run_epoch calls at the end of an epoch
+    mol, _ = _fwd_loss_skip(model, mtype, ds, 0.04, True)
+    mol.sum().backward()
     with pytest.raises(_lib.GctError, match="skipped"):
         _fwd_loss_skip(model, mtype, ds, 0.04, True)
     assert int(ops.skipped_row_gradients().item()) == 0   # reported once, then cleared
     mol, loss = _fwd_loss_skip(model, mtype, ds, 0.04, True)
+    opt.zero_grad(set_to_none=True)
     loss.backward()
+    opt.step()                                            # counter is zero: the guarded step updates as usual
+    assert not torch.equal(model.flat_params(), before)
     _fwd_loss_skip(model, mtype, ds, 0.04, True)          # the reference's loss: nothing to report
 
 
