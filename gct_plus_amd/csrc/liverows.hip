@@ -199,17 +199,28 @@ __global__ __launch_bounds__(256) void scatter_add_quads_kernel(const float* __r
 // zero the rows of a compact buffer that belong to no sample's live prefix: [cstart[b] + n_b[b], cstart[b + 1]) for every
 // sample (the padded rows that travel with a live quad) and everything behind the last sample up to `nrows` (the -1
 // padding quads).  A handful of rows per sample instead of a fill of the whole buffer.
+// Blocks [0, B): sample b's gap.  The LAST sample's gap runs to `nrows` (the padding quads and the slack rows behind the
+// compact rows: a few hundred rows, where every other gap is at most three) -- it is shared by the ZG_TAIL extra blocks
+// [B, B + ZG_TAIL) instead of being one workgroup's serial loop (that block alone took 10 us per launch, 36 launches a step).
+constexpr int ZG_TAIL = 48;
 __global__ __launch_bounds__(256) void zero_gap_rows_kernel(float* __restrict__ buf, int64_t ld, int c4,
                                                             const int32_t* __restrict__ cstart,
                                                             const int32_t* __restrict__ n_b, int B, int64_t nrows) {
-  const int b = blockIdx.x;
-  const int64_t r0 = (int64_t)cstart[b] + n_b[b];
-  const int64_t r1 = b + 1 < B ? (int64_t)cstart[b + 1] : nrows;
-  const int64_t total = (r1 - r0) * c4;
-  for (int64_t i = threadIdx.x; i < total; i += 256) {
-    const int64_t row = r0 + i / c4;
-    const int c = (int)(i % c4);
-    *reinterpret_cast<float4*>(buf + row * ld + c * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  int b = blockIdx.x;
+  int64_t r0, r1;
+  if (b < B - 1) {
+    r0 = (int64_t)cstart[b] + n_b[b];
+    r1 = (int64_t)cstart[b + 1];
+  } else {
+    const int part = b < B ? 0 : b - B + 1;                 // block B - 1 and the ZG_TAIL extra ones share the tail
+    const int64_t t0 = (int64_t)cstart[B - 1] + n_b[B - 1];
+    const int64_t len = nrows > t0 ? nrows - t0 : 0, per = (len + ZG_TAIL) / (ZG_TAIL + 1);
+    r0 = t0 + part * per;
+    r1 = r0 + per < nrows ? r0 + per : nrows;
+  }
+  for (int64_t row = r0; row < r1; ++row) {
+    float* p = buf + row * ld;
+    for (int c = threadIdx.x; c < c4; c += 256) *reinterpret_cast<float4*>(p + c * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
@@ -463,8 +474,8 @@ extern "C" int gct_zero_gap_rows(float* buf, int64_t ld, int cols, const int32_t
   GCT_CHECK_ARG(buf && cstart && n_b && B >= 0 && nrows >= 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 && gct_aligned16(buf),
                 "zero_gap_rows: bad args");
   if (B == 0) return GCT_OK;
-  hipLaunchKernelGGL(zero_gap_rows_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, buf, ld, cols / 4, cstart,
-                     n_b, B, nrows);
+  hipLaunchKernelGGL(zero_gap_rows_kernel, dim3((unsigned)(B + ZG_TAIL)), dim3(256), 0, (hipStream_t)stream, buf, ld, cols / 4,
+                     cstart, n_b, B, nrows);
   GCT_LAUNCH_CHECK("zero_gap_rows");
   return GCT_OK;
 }

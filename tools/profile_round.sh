@@ -10,8 +10,12 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 echo "== kernel stats of the default bench command"
-timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py > $out/bench_line_profiled.json 2> $out/bench_profiled.err || exit 1
-args="--steps 2 --warmup 1 --no-cpu-baseline --no-alt-mode --no-decode --no-fixed-len-leg --no-kernel-timing"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py > $out/bench_line_profiled.json 2> $out/bench_profiled.err || exit 1
+echo "== kernel stats of the training step alone (13 + 3 steps, no other leg in the process)"
+only="--steps 13 --warmup 3 --no-cpu-baseline --no-alt-mode --no-decode --no-fixed-len-leg --no-model-types --no-trainer-loop --no-kernel-timing"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_only -- python3 $root/bench.py $only > $out/training_only_bench_line.json 2> $out/training_only.err || exit 1
+cp $(find $out/stats_only -name "*kernel_stats.csv" | head -1) $out/training_only_kernel_stats.csv
+args="--steps 2 --warmup 1 --no-cpu-baseline --no-alt-mode --no-decode --no-fixed-len-leg --no-model-types --no-trainer-loop --no-kernel-timing"
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT"; do
   n=$(echo $grp | cut -d' ' -f1)
   echo "== pmc pass $n"
