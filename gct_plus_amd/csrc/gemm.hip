@@ -861,6 +861,7 @@ int64_t g_x6_kernel_launches = 0;   // gemm_x6_kernel launches (a tail-balanced 
 // tools/gemm_lab.hip only: the persistent stream-K form of the forward / dgrad kernels (round-4 experiment, measured and
 // not adopted: profiles/r04_gemm_experiment_persistent_*.log).  Nothing of it is compiled into the library.
 #include "../../tools/gemm_x6p.inc"
+#include "../../tools/gemm_x6w.inc"      // one wave per SIMD (round-4 experiment, forward only): g_x6p_on == 2
 constexpr int X6P_SYNC_SLOTS = 32;
 int g_x6p_on = 0;
 int* g_x6p_counters = nullptr;
@@ -1413,8 +1414,11 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
     if ((A_KC || !B_KC) && x6_ok<MODE>(g, vec)) {
       ++g_gemm_launches[1];
 #ifdef GCT_LAB_X6P
+      if constexpr (MODE == X6_FWD) {
+        if (g_x6p_on == 2 && g.nsplit == 1 && g.epi < EPI_D0 && g.a_nper >= g.K) return launch_x6w<X6_FWD>(g, st);
+      }
       if constexpr (MODE != X6_WGRAD) {
-        if (g_x6p_on && x6p_ok<MODE>(g, vec)) {
+        if (g_x6p_on == 1 && x6p_ok<MODE>(g, vec)) {
           int taken = 0;
           const int rc = launch_x6p<MODE>(g, st, skinny_ws, ws_bytes, x6p_counter_slot(), &taken);
           if (rc || taken) return rc;
@@ -1561,7 +1565,7 @@ extern "C" int gct_gemm_set_mode(int mode) {
 extern "C" int gct_gemm_get_mode(void) { return gemm_mode(); }
 #ifdef GCT_LAB_X6P
 extern "C" int gct_gemm_set_persistent(int on) {
-  g_x6p_on = on ? 1 : 0;
+  g_x6p_on = on;
   return GCT_OK;
 }
 extern "C" int gct_gemm_set_sync_buffer(int32_t* buf, int64_t bytes) {

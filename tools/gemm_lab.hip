@@ -67,6 +67,7 @@ int main(int argc, char** argv) {
   const int64_t M = argc > 1 ? atoll(argv[1]) : 40960;
   const int reps = argc > 2 ? atoi(argv[2]) : 9;
   const std::string filt = argc > 3 ? argv[3] : "";
+  const int variant = argc > 4 ? atoi(argv[4]) : 1;      // 1: persistent stream-K launch, 2: one wave per SIMD (forward only)
   struct Shape { const char* name; int K, nper, nseg; };
   const Shape shapes[] = {{"qkv", 512, 512, 3}, {"out", 512, 512, 1}, {"ffn1", 512, 2048, 1}, {"ffn2", 2048, 512, 1}};
   const size_t maxn = (size_t)M * 2048;
@@ -116,7 +117,7 @@ int main(int argc, char** argv) {
       double tt[2];
       (void)hipMemset(y, 0xff, (size_t)M * N * 4); (void)hipMemset(yref, 0xff, (size_t)M * N * 4);
       timeab([&](int pers) {
-        gct_gemm_set_persistent(pers);
+        gct_gemm_set_persistent(pers ? variant : 0);
         float* yy = pers ? y : yref; float* pp = pers ? pre : pre_ref;
         float* yy1 = nseg > 1 ? yy + nper : nullptr; float* yy2 = nseg > 2 ? yy + 2 * nper : nullptr;
         int rc = gct_linear_fwd_p(x, K, M, K, w, w1, w2, K, wp, pstride, b, b1, b2, nseg, nper, yy, yy1, yy2, N, c.epi, resid, pp, c.p,
@@ -133,7 +134,7 @@ int main(int argc, char** argv) {
       double tt[2];
       (void)hipMemset(dx, 0xff, (size_t)M * K * 4); (void)hipMemset(yref, 0xff, (size_t)M * K * 4);
       timeab([&](int pers) {
-        gct_gemm_set_persistent(pers);
+        gct_gemm_set_persistent(pers ? variant : 0);
         float* dd = pers ? dx : yref;
         int rc = gct_linear_dgrad_p(resid, nseg > 1 ? resid + nper : nullptr, nseg > 2 ? resid + 2 * nper : nullptr, N, M, nseg, nper, w, w1, w2,
                                     K, wp, pstride, K, dd, K, c.epi, pre_ref, c.p, 3, 1, ws, wsb, nullptr, 0, nullptr);
