@@ -66,6 +66,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-decode", action="store_true", help="skip the decode block (configs[4] metric)")
     ap.add_argument("--no-model-types", action="store_true", help="skip the short legs of the other three model types")
     ap.add_argument("--no-trainer-loop", action="store_true", help="skip the Train.trainer1.run_epoch legs")
+    ap.add_argument("--all-legs", action="store_true",
+                    help="N > 1 runs skip the model_types and trainer_loop legs (the scaling runs measure the headline step and "
+                         "report the exchange; the 1-GPU line carries those legs) unless this is given")
     ap.add_argument("--decode-n", type=int, default=4096, help="sequences decoded per GPU (the sampler's n is a free parameter)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo only for the launcher tests")
@@ -708,7 +711,8 @@ def worker(a):
     # (Bashscript/train/train_vaetf.sh:10-18, train_scavaetf.sh:10-20), against the bare step of this file on the same
     # batches; and once behind the tokenizer + collate loader on synthetic SMILES strings
     tloop = None
-    if not cpu and not a.no_trainer_loop and not a.tiny:
+    side_legs = world == 1 or a.all_legs
+    if not cpu and not a.no_trainer_loop and not a.tiny and side_legs:
         tloop = trainer_loop_legs(a, inner, opt, state, step, region, fence, reduce_max, make_pool, dev, world, rank, nxt)
         nxt += 4000
         state["pool"] = pool
@@ -716,7 +720,7 @@ def worker(a):
     # the other model types (BASELINE configs[2] = pvaetf, the 1-GPU point of configs[3] = scavaetf, pscavaetf): short legs
     # on MOSES-like batches and on unpadded ones, same step, same pool logic
     others = None
-    if not cpu and not a.no_model_types and not a.tiny:
+    if not cpu and not a.no_model_types and not a.tiny and side_legs:
         others = {}
         for mt in ("vaetf", "pvaetf", "scavaetf", "pscavaetf"):
             if mt == mtype:
