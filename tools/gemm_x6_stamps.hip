@@ -64,12 +64,17 @@ static void run(int64_t M, int K, int N, int epi, int persistent = 0) {
   }
   std::vector<unsigned long long> hs(64 * 8 * 8);
   hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
-  double seg[8] = {0};
-  for (int wv = 0; wv < 64 * 8; ++wv) for (int i = 0; i < 8; ++i) seg[i] += (double)hs[wv * 8 + i] / (64 * 8);
+  double seg[8] = {0}, segg[2][8] = {{0}};          // all waves; waves 0-3 / 4-7 (the two waves of a SIMD are w and w + 4)
+  for (int wv = 0; wv < 64 * 8; ++wv) for (int i = 0; i < 8; ++i) {
+    seg[i] += (double)hs[wv * 8 + i] / (64 * 8);
+    segg[(wv & 7) >> 2][i] += (double)hs[wv * 8 + i] / (64 * 4);
+  }
   double tot = 0; for (int i = 0; i < 8; ++i) tot += seg[i];
   const char* nm[8] = {"prologue", "first half", "barrier", "second half", "pre-epilogue sync", "epilogue(+stores)", "-", "-"};
   printf("M=%ld K=%d N=%d epi=%d: wave lifetime %.0f cycles, k-tiles %d\n", (long)M, K, N, epi, tot, K / 32);
-  for (int i = 0; i < 6; ++i) printf("   %-18s %9.0f cyc  %5.1f %%   (%.0f per k-tile)\n", nm[i], seg[i], 100 * seg[i] / tot, seg[i] / (K / 32));
+  for (int i = 0; i < 6; ++i)
+    printf("   %-18s %9.0f cyc  %5.1f %%   (%.0f per k-tile; waves 0-3: %.0f, waves 4-7: %.0f)\n", nm[i], seg[i], 100 * seg[i] / tot,
+           seg[i] / (K / 32), segg[0][i] / (K / 32), segg[1][i] / (K / 32));
   hipFree(x); hipFree(w); hipFree(b); hipFree(y); hipFree(pre); hipFree(wp); hipFree(st);
 }
 
