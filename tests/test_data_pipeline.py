@@ -79,3 +79,26 @@ def test_loader_scaffold_batches_and_sharding(tmp_path):
             seen.append(b["econds"][:, 0])
     got = sorted(round(float(x) * 10) for x in torch.cat(seen))
     assert got == list(range(len(SMILES)))                         # the two shards cover the data once
+
+
+def test_bench_synthetic_smiles_fill_the_benchmarked_vocabularies(tmp_path):
+    """bench.py's trainer_loop leg runs run_epoch behind the tokenizer + collate loader on synthetic SMILES strings: the
+    vocabularies built from them must have exactly the 28 / 30 entries of the synthetic token batches (so that the
+    benchmarked model can consume them and the leg is not skipped), and a collated batch must have the trainer's layout."""
+    import importlib.util
+    import os
+    import torch
+    from gct_plus_amd import data, synthetic
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    frame = mod.synthetic_smiles_frame(600, seed=3)
+    SRC, TRG, add_sep = data.get_fields("vaetf", str(tmp_path / "utils"), frame["src"].tolist())
+    assert (len(SRC), len(TRG)) == synthetic.vocab_sizes("vaetf") and not add_sep
+    ld = data.SmilesLoader(frame, SRC, TRG, "vaetf", [], 64, 0, 1, shuffle=False, seed=0, device=torch.device("cpu"))
+    b = next(iter(ld))
+    assert b["src"].shape[0] == 64 and b["trg"].shape == (64, b["src"].shape[1] + 2)
+    assert int(b["src"].max()) < len(SRC) and int(b["trg"].max()) < len(TRG)
+    assert (b["trg"][:, 0] == TRG.stoi["<sos>"]).all()
+    lens = (b["src"] != SRC.stoi["<pad>"]).sum(1)
+    assert 15 <= int(lens.min()) and int(lens.max()) <= 78
