@@ -791,6 +791,11 @@ def worker(a):
                 "final_loss_per_sample": round(final_loss, 4),
                 "roofline": roof,
             }
+            try:                                       # which box is this: the matrix rate it sustains (diagnostics library)
+                from gct_plus_amd import graphdiag
+                out["box"] = graphdiag.mfma_probe()
+            except Exception as exc:                   # noqa: BLE001 -- calibration only, never a reason to lose the line
+                out["box"] = {"error": repr(exc)}
             if not a.dense_decoder:
                 out["rows_not_computed"] = (
                     "as Train/trainer1.run_epoch runs it: decoder rows whose target is <pad> (ignore_index in the loss) "

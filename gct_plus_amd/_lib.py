@@ -121,6 +121,7 @@ DIAG_SIGNATURES = {
     "gct_graph_probe": (I32, [I32, I32, I32, P, P, P]),
     "gct_device_facts": (I32, [C.c_char_p, I32]),
     "gct_graph_census": (I32, [P, P]),
+    "gct_mfma_clock_probe": (I32, [I32, P, P]),
 }
 _diag = None
 

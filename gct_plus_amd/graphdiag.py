@@ -74,6 +74,15 @@ def micro_probe(nodes: int = 70, reps: int = 20, variants=(0, 1, 2, 3)) -> dict:
     return out
 
 
+def mfma_probe(iters: int = 20000) -> dict:
+    """Box calibration (gct_mfma_clock_probe): the bf16 MFMA rate this device sustains on a register-only loop."""
+    tf, ms = ctypes.c_float(), ctypes.c_float()
+    check(load().gct_mfma_clock_probe(int(iters), ctypes.byref(tf), ctypes.byref(ms)), "gct_mfma_clock_probe")
+    return {"bf16_mfma_tflops": round(tf.value, 1), "ms": round(ms.value, 3), "iters": int(iters),
+            "what": "register-only v_mfma_f32_16x16x32_bf16 loop, two waves per SIMD on every CU, pseudo-random operands "
+                    "(dense peak ~2500): devices of one pool differ by ~10 % here and so does the training step"}
+
+
 def census(torch_graph) -> dict | None:
     """Node census of a torch.cuda.CUDAGraph created with keep_graph=True (None if the handle is not available)."""
     try:

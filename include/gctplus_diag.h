@@ -26,6 +26,12 @@ int gct_graph_probe(int variant, int nodes, int reps, float* eager_ms, float* gr
 int gct_device_facts(char* buf, int cap);
 int gct_graph_census(void* hip_graph, int64_t* out8);
 
+/* Box calibration: the bf16 MFMA rate (TFLOP/s, dense peak ~2 500) this device sustains on a register-only loop of
+ * v_mfma_f32_16x16x32_bf16 (two waves per SIMD on every CU, pseudo-random operands, `iters` x 8 MFMAs per wave; best of
+ * three timed launches on a private stream, ms_out nullable).  Devices of one pool differ by ~10 % here, and so does
+ * the matrix-bound training step: a bench line quotes this figure so that two boxes can be told from two code versions. */
+int gct_mfma_clock_probe(int iters, float* tflops, float* ms_out);
+
 #ifdef __cplusplus
 }
 #endif
