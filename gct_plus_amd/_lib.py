@@ -80,10 +80,14 @@ SIGNATURES = {
     "gct_small_linear_fwd": (I32, [P, P, P, P, I32, I32, I32, P]),
     "gct_small_linear_bwd": (I32, [P, P, P, P, I32, I32, I32, P]),
     "gct_reduce_slabs": (I32, [P, I32, I64, P, I64, I32, P]),
+    "gct_reduce_defer_begin": (I32, []),
+    "gct_reduce_defer_flush": (I32, [P]),
+    "gct_reduce_defer_end": (I32, [P]),
+    "gct_reduce_defer_pending": (I32, []),
     "gct_add": (I32, [P, P, P, I64, P]),
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 _lib = None
 
 

@@ -84,12 +84,82 @@ __global__ __launch_bounds__(256) void reduce_slabs2_kernel(const ReduceRegion a
                           gridDim.x - ga);
 }
 
+// Deferred reductions.  A layer's backward pass ends 5-7 weight-gradient GEMMs and 2-3 Norm backward kernels with a slab
+// reduction each (74 + 32 launches of 5-10 us per step, each at 0.43 of the HBM rate because it is all ramp and tail).
+// Between gct_reduce_defer_begin() and gct_reduce_defer_end() every float4-shaped reduction of this file is recorded
+// instead of launched, and gct_reduce_defer_flush() runs all recorded ones as ONE launch (same lanes, same summation
+// order per region: bit-identical results).  The caller keeps every recorded job's slabs intact until the flush
+// (gct_plus_amd/ops.py hands out distinct workspace regions while deferral is on).  Thread-local: the recording thread
+// is the one that flushes (autograd's backward thread).
+struct ReduceJob {
+  const float* slabs;
+  float *d0, *d1, *d2;
+  int64_t stride, nper, n4;
+  int32_t nslab, sl;          // sl: slab lanes of the region (4 / 16 / 64)
+};
+constexpr int RJ_MAX = 24;    // jobs per launch (kernel-argument space)
+struct ReduceJobs {
+  ReduceJob j[RJ_MAX];
+  uint32_t first[RJ_MAX + 1]; // first block of each job
+  int32_t n;
+};
+__global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceJobs a) {
+  __shared__ float4 red[256];
+  int k = 0;
+#pragma unroll 1
+  for (int i = 1; i < a.n; ++i)
+    if (blockIdx.x >= a.first[i]) k = i;
+  const ReduceJob& j = a.j[k];
+  const unsigned bid = blockIdx.x - a.first[k], nblk = a.first[k + 1] - a.first[k];
+  if (j.sl == 4) reduce_slabs_body<4>(red, j.slabs, j.nslab, j.stride, j.d0, j.d1, j.d2, j.nper, j.n4, 0, bid, nblk);
+  else if (j.sl == 16) reduce_slabs_body<16>(red, j.slabs, j.nslab, j.stride, j.d0, j.d1, j.d2, j.nper, j.n4, 0, bid, nblk);
+  else reduce_slabs_body<64>(red, j.slabs, j.nslab, j.stride, j.d0, j.d1, j.d2, j.nper, j.n4, 0, bid, nblk);
+}
+
+thread_local bool t_defer = false;
+thread_local int t_njobs = 0;
+thread_local ReduceJob t_jobs[4 * RJ_MAX];
+
+inline unsigned rj_blocks(const ReduceJob& j) {
+  const int cw = 256 / j.sl;
+  int64_t g = (j.n4 + cw - 1) / cw;
+  const int64_t cap = j.sl == 4 ? 8192 : 1024;
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+int flush_jobs(hipStream_t st) {
+  for (int base = 0; base < t_njobs; base += RJ_MAX) {
+    ReduceJobs a;
+    a.n = t_njobs - base < RJ_MAX ? t_njobs - base : RJ_MAX;
+    unsigned nb = 0;
+    for (int i = 0; i < a.n; ++i) {
+      a.j[i] = t_jobs[base + i];
+      a.first[i] = nb;
+      nb += rj_blocks(a.j[i]);
+    }
+    for (int i = a.n; i <= RJ_MAX; ++i) a.first[i] = nb;
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3(nb), dim3(256), 0, st, a);
+  }
+  t_njobs = 0;
+  GCT_LAUNCH_CHECK("reduce_multi");
+  return GCT_OK;
+}
+// records the job (true) or tells the caller to launch it now (deferral off / table full)
+inline bool defer_job(const float* slabs, int nslab, int64_t stride, float* d0, float* d1, float* d2, int64_t nper,
+                      int64_t n4, int sl) {
+  if (!t_defer || t_njobs >= 4 * RJ_MAX) return false;
+  t_jobs[t_njobs++] = ReduceJob{slabs, d0, d1, d2, stride, nper, n4, nslab, sl};
+  return true;
+}
+
 static int launch_reduce(const float* slabs, int nslab, int64_t stride, float* d0, float* d1,
                          float* d2, int64_t nper, int64_t n4, int accumulate, hipStream_t st) {
   auto grid = [&](int cw) {
     int64_t g = (n4 + cw - 1) / cw;
     return dim3((unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g)));
   };
+  const int sl = (n4 >= 16384 || nslab <= 4) ? 4 : ((n4 >= 1024 || nslab <= 16) ? 16 : 64);
+  if (!accumulate && defer_job(slabs, nslab, stride, d0, d1, d2, nper, n4, sl)) return 0;
+  if (accumulate && t_njobs > 0) flush_jobs(st);     // an accumulation may target a recorded destination: keep the order
   if (n4 >= 16384 || nslab <= 4)
     hipLaunchKernelGGL(reduce_slabs_kernel<4>, grid(64), dim3(256), 0, st, slabs, nslab, stride, d0,
                        d1, d2, nper, n4, accumulate);
@@ -268,6 +338,11 @@ int gct_reduce_slabs_seg2(const float* sa, int nslab, int64_t stride_a, float* a
     if (rc) return rc;
     return gct_reduce_slabs_seg(sb, nslab, stride_b, b0, b1, b2, nper_b, nb, st);
   }
+  if (t_defer && t_njobs + 2 <= 4 * RJ_MAX) {        // same lanes as the launch below: 4 for the weights, 64 for the bias
+    defer_job(sa, nslab, stride_a, a0, a1, a2, nper_a, na / 4, 4);
+    defer_job(sb, nslab, stride_b, b0, b1, b2, nper_b, nb / 4, 64);
+    return GCT_OK;
+  }
   const ReduceRegion ra = {sa, stride_a, a0, a1, a2, nper_a, na / 4}, rb = {sb, stride_b, b0, b1, b2, nper_b, nb / 4};
   int64_t ga = (ra.n4 + 63) / 64, gb = (rb.n4 + 3) / 4;
   if (ga > 8192) ga = 8192;
@@ -310,7 +385,12 @@ int gct_colsum(const float* y0, const float* y1, const float* y2, int64_t ld, in
   hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, st, y0, y1, y2, ld, M,
                      (int64_t)nper, N, rpc > 0 ? rpc : 1, ws);
   GCT_LAUNCH_CHECK("colsum_partial");
-  return gct_reduce_slabs_seg(ws, chunks, N, d0, d1, d2, nper, N, st);
+  // never deferred: linear_wgrad lends this pass the workspace that its GEMM overwrites right afterwards
+  const bool keep = t_defer;
+  t_defer = false;
+  const int rc = gct_reduce_slabs_seg(ws, chunks, N, d0, d1, d2, nper, N, st);
+  t_defer = keep;
+  return rc;
 }
 
 extern "C" int64_t gct_rowred_ws_bytes(int64_t rows, int64_t cols) {
@@ -384,3 +464,21 @@ extern "C" int gct_nonzero_row_tiles(const float* x, int64_t ld, int64_t rows, i
   GCT_LAUNCH_CHECK("compact_flags");
   return GCT_OK;
 }
+
+/* Deferred slab reductions (see reduce_multi_kernel): between begin and end every float4-shaped slab reduction issued by
+ * this thread through the library (weight-gradient slabs, bias sums, Norm alpha / bias partials) is recorded instead of
+ * launched; flush runs the recorded ones as one launch on `stream` and keeps recording; end flushes and stops. */
+extern "C" int gct_reduce_defer_begin(void) {
+  t_defer = true;
+  return GCT_OK;
+}
+extern "C" int gct_reduce_defer_flush(void* stream) {
+  if (t_njobs == 0) return GCT_OK;
+  return flush_jobs((hipStream_t)stream);
+}
+extern "C" int gct_reduce_defer_end(void* stream) {
+  t_defer = false;
+  if (t_njobs == 0) return GCT_OK;
+  return flush_jobs((hipStream_t)stream);
+}
+extern "C" int gct_reduce_defer_pending(void) { return t_njobs; }

@@ -353,16 +353,17 @@ def enc_layer_bwd(run: Run, layer, saved, g, G: GradSink, gd=None, gdbuf=None, b
     [M,d] for the fused dropout_bwd outputs; below: saved FFN state of the layer underneath (its dropout_bwd is
     written by this layer's last Norm backward) -- returns (g, that buffer or None)."""
     x_in, m1, r1, sv_a, a, m2, r2, sv_f = saved
-    # out = n2 + drop(ffn(n2))  =>  d(n2) = g + ffn'(g): the W1 dgrad accumulates into g
-    ffn_bwd(run, layer.ff, sv_f, g, G, g, ops.DEPI_ACCUM, gdrop=gd)
-    dr = _mha_drop(run, sv_a, gdbuf)
-    ops.norm_bwd(g, a, layer.norm_2.alpha, m2, r2, G(layer.norm_2.alpha), G(layer.norm_2.bias),
-                 out=g, eps=layer.norm_2.eps, drop=dr)
-    # a = n1 + drop(attn(n1))
-    mha_bwd(run, layer.attn, sv_a, g, G, g, ops.DEPI_ACCUM, gdrop=None if dr is None else gdbuf)
-    dr = _ffn_drop(run, below, gdbuf)
-    ops.norm_bwd(g, x_in, layer.norm_1.alpha, m1, r1, G(layer.norm_1.alpha), G(layer.norm_1.bias),
-                 out=g, eps=layer.norm_1.eps, drop=dr)
+    with ops.deferred_reductions():      # the layer's 6 weight / bias / Norm slab reductions: one launch at the end
+        # out = n2 + drop(ffn(n2))  =>  d(n2) = g + ffn'(g): the W1 dgrad accumulates into g
+        ffn_bwd(run, layer.ff, sv_f, g, G, g, ops.DEPI_ACCUM, gdrop=gd)
+        dr = _mha_drop(run, sv_a, gdbuf)
+        ops.norm_bwd(g, a, layer.norm_2.alpha, m2, r2, G(layer.norm_2.alpha), G(layer.norm_2.bias),
+                     out=g, eps=layer.norm_2.eps, drop=dr)
+        # a = n1 + drop(attn(n1))
+        mha_bwd(run, layer.attn, sv_a, g, G, g, ops.DEPI_ACCUM, gdrop=None if dr is None else gdbuf)
+        dr = _ffn_drop(run, below, gdbuf)
+        ops.norm_bwd(g, x_in, layer.norm_1.alpha, m1, r1, G(layer.norm_1.alpha), G(layer.norm_1.bias),
+                     out=g, eps=layer.norm_1.eps, drop=dr)
     _grads_done(layer, G)
     return g, (None if dr is None else gdbuf)
 
@@ -383,19 +384,20 @@ def dec_layer_bwd(run: Run, layer, saved, g, de, first_de, G: GradSink, live=Non
     gd / gdbuf / below as in enc_layer_bwd; returns (g, dropout_bwd(g) for the FFN of the layer underneath or None)."""
     x, m1, r1, sv1, xa, m2, r2, sv2, xb, m3, r3, svf = saved
     t = torch.empty_like(g) if live is None else live.empty(g.shape[1])
-    ffn_bwd(run, layer.ff, svf, g, G, t, ops.DEPI_STORE, live=live, gdrop=gd)
-    dr = _mha_drop(run, sv2, gdbuf)
-    ops.norm_bwd(t, xb, layer.norm_3.alpha, m3, r3, G(layer.norm_3.alpha), G(layer.norm_3.bias),
-                 dres=g, out=g, eps=layer.norm_3.eps, live=live, drop=dr)
-    mha_bwd(run, layer.attn_2, sv2, g, G, t, ops.DEPI_STORE, de,
-            ops.DEPI_STORE if first_de else ops.DEPI_ACCUM, live=live, gdrop=None if dr is None else gdbuf)
-    dr = _mha_drop(run, sv1, gdbuf)
-    ops.norm_bwd(t, xa, layer.norm_2.alpha, m2, r2, G(layer.norm_2.alpha), G(layer.norm_2.bias),
-                 dres=g, out=g, eps=layer.norm_2.eps, live=live, drop=dr)
-    mha_bwd(run, layer.attn_1, sv1, g, G, t, ops.DEPI_STORE, live=live, gdrop=None if dr is None else gdbuf)
-    dr = _ffn_drop(run, below, gdbuf)
-    ops.norm_bwd(t, x, layer.norm_1.alpha, m1, r1, G(layer.norm_1.alpha), G(layer.norm_1.bias),
-                 dres=g, out=g, eps=layer.norm_1.eps, live=live, drop=dr)
+    with ops.deferred_reductions():      # the layer's 9 weight / bias / Norm slab reductions: one launch at the end
+        ffn_bwd(run, layer.ff, svf, g, G, t, ops.DEPI_STORE, live=live, gdrop=gd)
+        dr = _mha_drop(run, sv2, gdbuf)
+        ops.norm_bwd(t, xb, layer.norm_3.alpha, m3, r3, G(layer.norm_3.alpha), G(layer.norm_3.bias),
+                     dres=g, out=g, eps=layer.norm_3.eps, live=live, drop=dr)
+        mha_bwd(run, layer.attn_2, sv2, g, G, t, ops.DEPI_STORE, de,
+                ops.DEPI_STORE if first_de else ops.DEPI_ACCUM, live=live, gdrop=None if dr is None else gdbuf)
+        dr = _mha_drop(run, sv1, gdbuf)
+        ops.norm_bwd(t, xa, layer.norm_2.alpha, m2, r2, G(layer.norm_2.alpha), G(layer.norm_2.bias),
+                     dres=g, out=g, eps=layer.norm_2.eps, live=live, drop=dr)
+        mha_bwd(run, layer.attn_1, sv1, g, G, t, ops.DEPI_STORE, live=live, gdrop=None if dr is None else gdbuf)
+        dr = _ffn_drop(run, below, gdbuf)
+        ops.norm_bwd(t, x, layer.norm_1.alpha, m1, r1, G(layer.norm_1.alpha), G(layer.norm_1.bias),
+                     dres=g, out=g, eps=layer.norm_1.eps, live=live, drop=dr)
     _grads_done(layer, G)
     return g, (None if dr is None else gdbuf)
 

@@ -107,6 +107,62 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return buf
 
 
+# Deferred slab reductions (csrc/reduce.hip): a layer's backward pass records the reductions that end its weight-gradient
+# GEMMs and Norm backward kernels and runs them as ONE launch at the end of the layer (engine.enc_layer_bwd /
+# dec_layer_bwd): 106 launches of 5-10 us per step become 12.  While recording, the workspaces of those calls must stay
+# intact until the flush: kept_workspace() hands out consecutive regions of a second buffer instead of the shared one.
+DEFER_REDUCTIONS = os.environ.get("GCT_DEFER_REDUCTIONS", "1") != "0"
+_DEFER = {"on": False, "off": 0, "demand": 0, "want": 0}
+_ARENA = {}
+
+
+def kept_workspace(nbytes: int, device) -> torch.Tensor:
+    """Workspace of a call whose slab reduction may be deferred: the shared scratch buffer when nothing is being
+    recorded, otherwise a fresh region of the arena (the recorded reductions are flushed first when it is full)."""
+    if not _DEFER["on"]:
+        return workspace(nbytes, device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _st())
+    n = (int(nbytes) + 255) // 256 * 64            # floats, 256-byte regions
+    _DEFER["demand"] += n
+    buf = _ARENA.get(key)
+    if buf is None or _DEFER["off"] + n > buf.numel():
+        # full (or absent): what was recorded so far is reduced now, on this stream, before anything overwrites it
+        check(_L().gct_reduce_defer_flush(_st()), "gct_reduce_defer_flush")
+        _DEFER["off"] = 0
+        if buf is None or n > buf.numel():
+            buf = _ARENA[key] = torch.empty(max(n, _DEFER["want"], 1 << 22), dtype=torch.float32, device=device)
+    out = buf[_DEFER["off"]:_DEFER["off"] + n]
+    _DEFER["off"] += n
+    return out
+
+
+class deferred_reductions:
+    """with deferred_reductions(): ... -- the slab reductions issued inside by THIS thread run as one launch at exit
+    (bit-identical results: same lanes and summation order per destination).  Not while a graph is being captured, not
+    with the side stream (its weight gradients are ordered by events, not by this stream), not nested."""
+
+    def __enter__(self):
+        self.mine = (DEFER_REDUCTIONS and not _DEFER["on"] and not SIDE_ENABLED
+                     and not torch.cuda.is_current_stream_capturing())
+        if self.mine:
+            key = (torch.cuda.current_device(), _st())
+            buf = _ARENA.get(key)
+            if buf is not None and buf.numel() < _DEFER["want"]:
+                del _ARENA[key]                    # grown on first use below: a whole layer fits from the second layer on
+            _DEFER.update(on=True, off=0, demand=0)
+            check(_L().gct_reduce_defer_begin(), "gct_reduce_defer_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.mine:
+            _DEFER["on"] = False
+            _DEFER["want"] = max(_DEFER["want"], _DEFER["demand"])
+            rc = _L().gct_reduce_defer_end(_st())
+            if et is None:
+                check(rc, "gct_reduce_defer_end")
+        return False
+
+
 _WS_NEED = {}
 
 
@@ -144,7 +200,7 @@ def norm_bwd(dy, x2d, alpha, mean, rstd, dalpha, dbias, dres=None, out=None, eps
     _wait_pending(out)
     if drop is not None:
         _wait_pending(drop[0])
-    ws = workspace(_L().gct_rowred_ws_bytes(rows, 2 * d), x2d.device)
+    ws = kept_workspace(_L().gct_rowred_ws_bytes(rows, 2 * d), x2d.device)
     check(_L().gct_norm_bwd(_p(dy), _p(x2d), _p(alpha), _p(mean), _p(rstd), _p(dres), _p(dx),
                             _p(dalpha), _p(dbias), _p(ws), rows, d, eps,
                             None if live is None else _p(live.quad_list), src_rows,
@@ -531,7 +587,7 @@ def linear_wgrad(dys: Sequence[torch.Tensor], lddy: int, x2d, dws: Sequence[torc
     db = _seg3(dbs)
 
     def launch():
-        ws = workspace(_ws_need("gct_wgrad_ws_bytes", M, nseg * nper, K), x2d.device)
+        ws = kept_workspace(_ws_need("gct_wgrad_ws_bytes", M, nseg * nper, K), x2d.device)
         with _Timed("gemm_wgrad+bias+reduce", 2.0 * M * K * nper * nseg):
             check(_L().gct_linear_wgrad_kt(d[0], d[1], d[2], lddy, M, nseg, nper, _p(x2d), x2d.stride(0),
                                            K, dw[0], dw[1], dw[2], K, db[0], db[1], db[2], _p(ws),

@@ -37,7 +37,7 @@ extern "C" {
 #define GCT_ERR_ARG (-1)  /* bad shape / alignment / null pointer            */
 #define GCT_ERR_HIP (-2)  /* a HIP runtime call failed (launch error)        */
 
-#define GCT_ABI_VERSION 12
+#define GCT_ABI_VERSION 13
 
 int gct_version(void);
 const char* gct_last_error(void);
@@ -417,6 +417,17 @@ int gct_small_linear_bwd(const float* dy, const float* x, float* dw, float* db, 
 /* dst[i] = sum_s slabs[s*stride + i] (deterministic slab reduction) */
 int gct_reduce_slabs(const float* slabs, int nslab, int64_t stride, float* dst, int64_t n,
                      int accumulate, void* stream);
+/* Deferred slab reductions: between gct_reduce_defer_begin and gct_reduce_defer_end every float4-shaped slab reduction
+ * that the calling THREAD issues through this library (the tails of gct_linear_wgrad*, gct_norm_bwd's alpha / bias
+ * partials, bias column sums) is recorded instead of launched; gct_reduce_defer_flush launches all recorded ones as ONE
+ * kernel on `stream` (same summation order per region: results are bit-identical) and keeps recording, _end flushes and
+ * stops, _pending returns the number recorded.  Contract: the caller keeps every recorded call's workspace intact until
+ * the flush and does not read the destinations before it (a layer's parameter gradients: engine.py flushes at the end of
+ * each layer's backward pass, before the data-parallel exchange may start). */
+int gct_reduce_defer_begin(void);
+int gct_reduce_defer_flush(void* stream);
+int gct_reduce_defer_end(void* stream);
+int gct_reduce_defer_pending(void);
 /* y = a + b (gradient joins of the residual stream) */
 int gct_add(const float* a, const float* b, float* y, int64_t n, void* stream);
 

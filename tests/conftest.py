@@ -26,7 +26,7 @@ def _module_switches_restored():
     from gct_plus_amd import engine, ops
     names = [n for n in dir(engine) if n.startswith("COMPACT_")]
     keep = {n: getattr(engine, n) for n in names}
-    side = ops.SIDE_ENABLED
+    side, defer = ops.SIDE_ENABLED, ops.DEFER_REDUCTIONS
     mode = None
     try:
         import torch
@@ -37,6 +37,6 @@ def _module_switches_restored():
     yield
     for n, v in keep.items():
         setattr(engine, n, v)
-    ops.SIDE_ENABLED = side
+    ops.SIDE_ENABLED, ops.DEFER_REDUCTIONS = side, defer
     if mode is not None and ops.gemm_get_mode() != mode:
         ops.gemm_set_mode(mode)

@@ -804,6 +804,33 @@ def test_side_stream_wgrad_gives_identical_gradients(golden_dir, monkeypatch):
         assert torch.equal(grads[0][k], grads[1][k]), k
 
 
+@pytest.mark.parametrize("mtype,full,batch", [("pscavaetf", False, 6), ("vaetf", True, 48), ("pvaetf", True, 24)])
+def test_deferred_slab_reductions_give_identical_gradients(mtype, full, batch, monkeypatch):
+    """The slab reductions of a layer's backward pass run as one launch at the end of the layer
+    (ops.deferred_reductions): same lanes and summation order per destination, so not a single bit may change against
+    the launch-per-reduction path -- with dropout on (the masks depend on the seed alone), over several passes (the
+    arena is sized by the first layer, recycled by the later ones) and with a batch change in between (regrowth)."""
+    from gct_plus_amd import ops
+    lib = ops._L()
+    grads = []
+    for defer in (False, True):
+        monkeypatch.setattr(ops, "DEFER_REDUCTIONS", defer)
+        model = build(mtype, dropout=0.1, full=full).train()
+        for it, n in enumerate((batch, batch, 2 * batch)):
+            ds = synthetic.make_dataset(n, max_len=40, model_type=mtype, seed=5 + it)
+            for p in model.parameters():
+                p.grad = None
+            torch.manual_seed(100 + it)
+            run_fwd_loss(model, mtype, ds, 0.3)[5].backward()
+            assert lib.gct_reduce_defer_pending() == 0
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys()
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+    assert not ops._DEFER["on"]
+
+
 def test_cond2dec_path_vs_reference(golden_dir):
     """HIP path with -use_cond2dec against the reference fixture: decoder cond tokens, [B,T+3,T+3]
     block mask, prop_fc head (N=1 GEMM) and the MSE term."""
