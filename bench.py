@@ -654,6 +654,11 @@ def worker(a):
         # kinds cost ~2 % of the step in event overhead); --all-kernel-timing restores the rest
         ops.PROFILE_KINDS = None if a.all_kernel_timing else {"gemm_fwd"}
     dt, last = region(a.warmup, a.steps)
+    host_main = {"ms_per_step": round(host["s"] / max(host["n"], 1) * 1e3, 3),
+                 "blocked_in_readback_ms_per_step": round(ops.HOST_BLOCKED_S[0] / max(host["n"], 1) * 1e3, 3) if ops else None,
+                 "note": "wall time this rank's Python spent inside the timed steps (ctypes launches, autograd, allocator) and "
+                         "the part of it spent waiting in the step's one device->host read-back; a step is host-bound when "
+                         "ms_per_step minus the wait approaches the step time"}
     prof = None
     if not cpu:
         prof, ops.PROFILE = ops.PROFILE, None
@@ -790,6 +795,7 @@ def worker(a):
                 "launcher": launcher,
                 "final_loss_per_sample": round(final_loss, 4),
                 "roofline": roof,
+                "host": host_main,
             }
             try:                                       # which box is this: the matrix rate it sustains (diagnostics library)
                 from gct_plus_amd import graphdiag

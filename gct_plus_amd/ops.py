@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import math
 import os
+import threading
 import weakref
 from typing import List, Optional, Sequence
 
@@ -112,27 +113,32 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 # dec_layer_bwd): 106 launches of 5-10 us per step become 12.  While recording, the workspaces of those calls must stay
 # intact until the flush: kept_workspace() hands out consecutive regions of a second buffer instead of the shared one.
 DEFER_REDUCTIONS = os.environ.get("GCT_DEFER_REDUCTIONS", "1") != "0"
-_DEFER = {"on": False, "off": 0, "demand": 0, "want": 0}
+class _DeferState(threading.local):        # per thread, like the library's record of pending reductions
+    def __init__(self):
+        self.d = {"on": False, "off": 0, "demand": 0, "want": 0}
+
+
+_DEFER_TL = _DeferState()
 _ARENA = {}
 
 
 def kept_workspace(nbytes: int, device) -> torch.Tensor:
     """Workspace of a call whose slab reduction may be deferred: the shared scratch buffer when nothing is being
     recorded, otherwise a fresh region of the arena (the recorded reductions are flushed first when it is full)."""
-    if not _DEFER["on"]:
+    if not _DEFER_TL.d["on"]:
         return workspace(nbytes, device)
     key = (device.index if device.index is not None else torch.cuda.current_device(), _st())
     n = (int(nbytes) + 255) // 256 * 64            # floats, 256-byte regions
-    _DEFER["demand"] += n
+    _DEFER_TL.d["demand"] += n
     buf = _ARENA.get(key)
-    if buf is None or _DEFER["off"] + n > buf.numel():
+    if buf is None or _DEFER_TL.d["off"] + n > buf.numel():
         # full (or absent): what was recorded so far is reduced now, on this stream, before anything overwrites it
         check(_L().gct_reduce_defer_flush(_st()), "gct_reduce_defer_flush")
-        _DEFER["off"] = 0
+        _DEFER_TL.d["off"] = 0
         if buf is None or n > buf.numel():
-            buf = _ARENA[key] = torch.empty(max(n, _DEFER["want"], 1 << 22), dtype=torch.float32, device=device)
-    out = buf[_DEFER["off"]:_DEFER["off"] + n]
-    _DEFER["off"] += n
+            buf = _ARENA[key] = torch.empty(max(n, _DEFER_TL.d["want"], 1 << 22), dtype=torch.float32, device=device)
+    out = buf[_DEFER_TL.d["off"]:_DEFER_TL.d["off"] + n]
+    _DEFER_TL.d["off"] += n
     return out
 
 
@@ -142,21 +148,21 @@ class deferred_reductions:
     with the side stream (its weight gradients are ordered by events, not by this stream), not nested."""
 
     def __enter__(self):
-        self.mine = (DEFER_REDUCTIONS and not _DEFER["on"] and not SIDE_ENABLED
+        self.mine = (DEFER_REDUCTIONS and not _DEFER_TL.d["on"] and not SIDE_ENABLED
                      and not torch.cuda.is_current_stream_capturing())
         if self.mine:
             key = (torch.cuda.current_device(), _st())
             buf = _ARENA.get(key)
-            if buf is not None and buf.numel() < _DEFER["want"]:
+            if buf is not None and buf.numel() < _DEFER_TL.d["want"]:
                 del _ARENA[key]                    # grown on first use below: a whole layer fits from the second layer on
-            _DEFER.update(on=True, off=0, demand=0)
+            _DEFER_TL.d.update(on=True, off=0, demand=0)
             check(_L().gct_reduce_defer_begin(), "gct_reduce_defer_begin")
         return self
 
     def __exit__(self, et, ev, tb):
         if self.mine:
-            _DEFER["on"] = False
-            _DEFER["want"] = max(_DEFER["want"], _DEFER["demand"])
+            _DEFER_TL.d["on"] = False
+            _DEFER_TL.d["want"] = max(_DEFER_TL.d["want"], _DEFER_TL.d["demand"])
             rc = _L().gct_reduce_defer_end(_st())
             if et is None:
                 check(rc, "gct_reduce_defer_end")

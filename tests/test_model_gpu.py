@@ -828,7 +828,7 @@ def test_deferred_slab_reductions_give_identical_gradients(mtype, full, batch, m
     assert grads[0].keys() == grads[1].keys()
     for k in grads[0]:
         assert torch.equal(grads[0][k], grads[1][k]), k
-    assert not ops._DEFER["on"]
+    assert not ops._DEFER_TL.d["on"]
 
 
 def test_cond2dec_path_vs_reference(golden_dir):
