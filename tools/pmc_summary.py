@@ -23,6 +23,7 @@ SHORT = [(r"gemm_x6_kernel<0>", "gemm_x6_kernel<0> (forward)"), (r"gemm_x6_kerne
          (r"gemm_x6s_kernel<0>", "gemm_x6s_kernel<0> (forward, 64x128 tiles)"),
          (r"gemm_x6s_kernel<1>", "gemm_x6s_kernel<1> (dgrad, 64x128 tiles)"),
          (r"splitk_epilogue_kernel", "splitk_epilogue_kernel"), (r"reduce_slabs2_kernel", "reduce_slabs2_kernel"),
+         (r"reduce_multi_kernel", "reduce_multi_kernel (a layer's slab reductions)"),
          (r"attn_fwd_kernel<4", "attn_fwd_kernel<4,..>"),
          (r"attn_bwd_kernel<4", "attn_bwd_kernel<4,..>"), (r"attn_fwd_direct_kernel<4", "attn_fwd_direct_kernel<4,6>"),
          (r"attn_bwd_dq_kernel<4", "attn_bwd_dq_kernel<4,6>"), (r"attn_bwd_dkv_kernel<4", "attn_bwd_dkv_kernel<4,6>"),
