@@ -862,6 +862,7 @@ int64_t g_x6_kernel_launches = 0;   // gemm_x6_kernel launches (a tail-balanced 
 // not adopted: profiles/r04_gemm_experiment_persistent_*.log).  Nothing of it is compiled into the library.
 #include "../../tools/gemm_x6p.inc"
 #include "../../tools/gemm_x6w.inc"      // one wave per SIMD (round-4 experiment, forward only): g_x6p_on == 2
+#include "../../tools/gemm_x6h.inc"      // two 4-wave workgroups per CU, 128 x 128 tiles (round-4 experiment, forward only): g_x6p_on == 4
 constexpr int X6P_SYNC_SLOTS = 32;
 int g_x6p_on = 0;
 int* g_x6p_counters = nullptr;
@@ -1416,6 +1417,13 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
 #ifdef GCT_LAB_X6P
       if constexpr (MODE == X6_FWD) {
         if (g_x6p_on == 2 && g.nsplit == 1 && g.epi < EPI_D0 && g.a_nper >= g.K) return launch_x6w<X6_FWD>(g, st);
+      }
+      if constexpr (MODE == X6_FWD) {          // lab variant 3: the 64 x 128-tile kernel (two workgroups per CU) for the whole problem
+        if (g_x6p_on == 3 && x6s_ok(g, vec)) return launch_x6s<X6_FWD>(g, st);
+        if (g_x6p_on == 4 && x6s_ok(g, vec)) return launch_x6h<X6_FWD>(g, st);
+      }
+      if constexpr (MODE == X6_DGRAD) {
+        if (g_x6p_on == 3 && x6s_dgrad_ok(g, vec)) return launch_x6s<X6_DGRAD>(g, st);
       }
       if constexpr (MODE != X6_WGRAD) {
         if (g_x6p_on == 1 && x6p_ok<MODE>(g, vec)) {
