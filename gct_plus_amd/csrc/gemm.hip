@@ -1324,6 +1324,12 @@ int launch(const GemmArgs& g, bool vec, hipStream_t st, float* skinny_ws = nullp
       ++g_gemm_launches[1];
       return launch_x6s(g, st);
     }
+    // weight segments of 128 rows (the sampler's mu | log_var, N = 2 x 128): not a whole number of 256-row tiles per
+    // segment, so the large kernel cannot take them -- the small-tile kernel for the whole problem instead of fp32 MFMA
+    if (x6s_on && !x6_ok<X6_FWD>(g, vec) && small >= 96 && x6s_ok(g, vec)) {
+      ++g_gemm_launches[1];
+      return launch_x6s(g, st);
+    }
     if (x6_ok<X6_FWD>(g, vec)) {
       int taken = 0;
       const int rc = launch_x6_splitk_all<X6_FWD>(g, st, skinny_ws, ws_bytes, &taken);
