@@ -461,8 +461,9 @@ def trainer_loop_legs(a, inner, opt, state, step, region, fence, reduce_max, mak
                                  lr_WarmUpSteps=8000, d_model=512, print_every=1)
     model = state.get("dp_model", inner)
     k = 20
-    res = {"steps": k, "note": "Train.trainer1.run_epoch (loss read-back, records.log line and LR write every step, -print_every "
-                               "1 as the reference's default) over batches staged in HBM vs this file's bare step on the same "
+    res = {"steps": k, "note": "Train.trainer1.run_epoch (the three loss scalars of every step read back -- one step late, behind the "
+                               "next step's row plan --, records.log line and LR write every step, -print_every 1 as the "
+                               "reference's default) over batches staged in HBM vs this file's bare step on the same "
                                "batches; ratio = bare / trainer (1.0: the loop costs nothing)"}
 
     def timed_epoch(loader, cur):

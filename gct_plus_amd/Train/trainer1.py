@@ -58,6 +58,25 @@ def run_epoch(args, model, optimizer, dataloader, current_step, beta, LOG, train
     cost_time = -time()
     nprop = len(args.property_list)
     n_batches = len(dataloader)
+    pending = []                 # steps whose three loss scalars are on their way to the host
+
+    def resolve():
+        while pending:
+            i_, n_, beta_, lr_, vals, ev = pending.pop(0)
+            if ev is not None:
+                ev.synchronize()
+            rce, kld, tot = vals.tolist()
+            history['RCE'].append(rce / n_)
+            history['KLD'].append(kld / n_)
+            history['LOSS'].append(tot / n_)
+            history['BETA'].append(beta_)
+            history['LR'].append(lr_)
+            if (i_ + 1) % every == 0:
+                LOG.info(f'{i_+1}/{n_batches:<10}\tRCE: {history["RCE"][-1]:.5f}\t'
+                         f'KLD: {history["KLD"][-1]:.5f}\tLOSS: {history["LOSS"][-1]:.5f}\t'
+                         f'TIME(s): {time() + cost_time:.1f}\tMODELTIME(s): {model_cost_time:.1f}\t'
+                         f'UPDATETIME(s): {update_cost_time:.1f}')
+
     for i, batch in enumerate(dataloader):
         current_step += 1
         n_onebatch = batch['src'].size(0)
@@ -67,6 +86,7 @@ def run_epoch(args, model, optimizer, dataloader, current_step, beta, LOG, train
         preds_prop, preds_mol, mu, log_var, _ = forward_propagation[args.model_type](
             model, batch, args.pad_id, args.use_cond2dec, skip_ignored=True)[:5]
         model_cost_time += time()
+        resolve()                # the previous step's scalars: already on the host
         ys_cond = batch['dconds'].unsqueeze(2).contiguous().view(-1, nprop, 1) if nprop > 0 else None
         ys_mol = batch['trg'][:, 1:].contiguous().view(-1)
         update_cost_time -= time()
@@ -86,17 +106,20 @@ def run_epoch(args, model, optimizer, dataloader, current_step, beta, LOG, train
                 g['lr'] = lr
         current_lr = optimizer.param_groups[-1]['lr']
         n_samples += n_onebatch
-        rce, kld, tot = torch.stack([RCE_mol.detach(), KLD.detach(), loss.detach()]).tolist()
-        history['RCE'].append(rce / n_onebatch)
-        history['KLD'].append(kld / n_onebatch)
-        history['LOSS'].append(tot / n_onebatch)
-        history['BETA'].append(beta)
-        history['LR'].append(current_lr)
-        if (i + 1) % every == 0:
-            LOG.info(f'{i+1}/{n_batches:<10}\tRCE: {history["RCE"][-1]:.5f}\t'
-                     f'KLD: {history["KLD"][-1]:.5f}\tLOSS: {history["LOSS"][-1]:.5f}\t'
-                     f'TIME(s): {time() + cost_time:.1f}\tMODELTIME(s): {model_cost_time:.1f}\t'
-                     f'UPDATETIME(s): {update_cost_time:.1f}')
+        scal = torch.stack([RCE_mol.detach(), KLD.detach(), loss.detach()])
+        if scal.is_cuda:
+            # the three scalars leave the device asynchronously and are READ one step later, after the next step's
+            # forward has been queued (its row plan is the step's one host synchronisation and completes behind this
+            # copy): the host never stops to wait for a loss, the history and the log lines are the same, one step late
+            host = torch.empty(3, dtype=scal.dtype, pin_memory=True)
+            host.copy_(scal, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            pending.append((i, n_onebatch, beta, current_lr, host, ev))
+        else:
+            pending.append((i, n_onebatch, beta, current_lr, scal, None))
+            resolve()
+    resolve()
     if train and next(model.parameters()).is_cuda:
         from .. import ops
         ops.assert_no_skipped_row_gradients()     # (every earlier step's counter was read with the next step's row plan)
