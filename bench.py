@@ -225,6 +225,13 @@ def hip_workload(a, dev, world, rank, mtype=None):
         loss, _, _, _ = loss_function(beta, prop, mol, ys_cond, ys, mu, lv, False, pad_id)
         return loss
     fwd_loss.model = model            # the data-parallel wrapper at N > 1 (what a trainer calls), else the model itself
+
+    def announce(batch):
+        # run_epoch's look-ahead: the next batch's masks and row maps are queued between this step's forward and its
+        # backward, so their read-back is on the host before the next forward asks for it
+        from gct_plus_amd.Model.forward_propagation1 import prefetch
+        prefetch(mtype, model, batch, pad_id, False, skip_ignored=not a.dense_decoder)
+    fwd_loss.prefetch = announce
     return inner, opt, fwd_loss
 
 
@@ -607,6 +614,9 @@ def worker(a):
     def _step(i):
         batch = state["pool"][i % len(state["pool"])]
         loss = state["fwd_loss"](batch)
+        ahead = getattr(state["fwd_loss"], "prefetch", None)
+        if ahead is not None:
+            ahead(state["pool"][(i + 1) % len(state["pool"])])
         o = state["opt"]
         o.zero_grad(set_to_none=True)
         loss.backward()

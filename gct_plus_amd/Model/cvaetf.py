@@ -9,7 +9,7 @@ from .. import engine, ops
 from ..flat import FlatModelMixin, planes_scope
 from .layers import DecoderLayer, EncoderLayer
 from .modules import Embeddings, Norm, PositionalEncoding, get_clones
-from .vaetf import Linear, _TrunkParams, _row_plan
+from .vaetf import Linear, _TrunkParams, _row_plan, _row_plan_launch
 
 
 class Encoder(nn.Module, _TrunkParams):
@@ -119,12 +119,16 @@ class Cvaetf(FlatModelMixin, nn.Module):
             x = x[0]
         return self.out(x)
 
+    def plan_ahead(self, src_mask, trg_mask, loss_rows, trg):
+        """As Vaetf.plan_ahead."""
+        return _row_plan_launch(self, src_mask, trg_mask, loss_rows, trg)
+
     @planes_scope
-    def forward(self, src, trg, src_mask, trg_mask, econds=None, dconds=None, *, loss_rows=None):
+    def forward(self, src, trg, src_mask, trg_mask, econds=None, dconds=None, *, loss_rows=None, _plan_ahead=None):
         """Reference signature (Model/cvaetf.py:179) plus the keyword-only loss_rows extension of Vaetf.forward."""
         if self.get_attn or (self.use_cond2dec and self.nconds > 0):
             loss_rows = None
-        plan = _row_plan(self, src_mask, trg_mask, loss_rows, trg)
+        plan = _plan_ahead.finish() if _plan_ahead is not None else _row_plan(self, src_mask, trg_mask, loss_rows, trg)
         z, mu, log_var = self.encoder(src, src_mask, econds, _keys=plan.enc_keys)[:3]
         d_output = self.decoder(trg, z, src_mask, trg_mask, dconds, loss_rows, _compact_out=True, _plan=plan)
         if self.get_attn:

@@ -102,20 +102,27 @@ class Decoder(nn.Module, _TrunkParams):
 def _row_plan(model, src_mask, trg_mask, loss_rows, trg):
     """engine.RowPlan of a training-style forward: the row maps of both trunks, read back in ONE synchronisation at the
     start of the step (see engine.RowPlan).  Works on the masks exactly as the caller passed them (Model/modules.py)."""
+    return _row_plan_launch(model, src_mask, trg_mask, loss_rows, trg).finish()
+
+
+def _row_plan_launch(model, src_mask, trg_mask, loss_rows, trg):
+    """The first half of _row_plan (engine.RowPlan.launch): kernels and the read-back are queued, .finish() gives the plan."""
+    if model.get_attn or (model.use_cond2dec and model.nconds > 0):
+        loss_rows = None
     if model.get_attn or src_mask is None or not src_mask.is_cuda:
-        return engine.RowPlan()
+        return engine._PendingPlan(None, None, None, None, 0, 0, 0)
     dec = model.decoder
     sm = ops.to_mask_u8(src_mask)
     B, T = trg.shape
     if sm.dim() != 3 or sm.shape[0] != B or sm.shape[1] != 1:          # not the reference's [B, 1, L] key-padding mask
-        return engine.RowPlan()
+        return engine._PendingPlan(None, None, None, None, 0, 0, 0)
     Le = sm.shape[2]
     c2d = dec.use_cond2dec and dec.nconds > 0
     nc_lat = dec.nconds if (not c2d and dec.use_cond2lat and dec.nconds > 0) else 0
     lr = None if loss_rows is None else loss_rows.to(torch.uint8).contiguous()
     tm = None if trg_mask is None else ops.to_mask_u8(trg_mask)
-    return engine.RowPlan.build(sm.view(B, Le), tm, lr, B, Le, T if not c2d else T + dec.nconds, nc_lat,
-                                len(model.encoder.layers), len(dec.layers))
+    return engine.RowPlan.launch(sm.view(B, Le), tm, lr, B, Le, T if not c2d else T + dec.nconds, nc_lat,
+                                 len(model.encoder.layers), len(dec.layers))
 
 
 class Linear(nn.Linear):
@@ -159,15 +166,20 @@ class Vaetf(FlatModelMixin, nn.Module):
             x = x[0]
         return self.out(x)
 
+    def plan_ahead(self, src_mask, trg_mask, loss_rows, trg):
+        """Queue the row maps of a batch that a later forward(..., _plan_ahead=<the returned object>) will use (the
+        trainer: the NEXT batch's, between this step's forward and its backward -- Model/forward_propagation1.prefetch)."""
+        return _row_plan_launch(self, src_mask, trg_mask, loss_rows, trg)
+
     @planes_scope
-    def forward(self, src, trg, src_mask, trg_mask, econds=None, dconds=None, *, loss_rows=None):
+    def forward(self, src, trg, src_mask, trg_mask, econds=None, dconds=None, *, loss_rows=None, _plan_ahead=None):
         """Reference signature (Model/vaetf.py:154) plus one keyword-only extension: loss_rows (bool [B, T]) names the
         decoder rows whose logits reach the loss -- the trainer passes `ys != pad` (Model/forward_propagation1.py); the
         other rows are then not computed at all: their logits come back as zeros -- or, for the few padded rows that share an
         aligned group of four with a live row, as arbitrary finite values -- NOT as the reference's values.  Default (None): every row, as the reference."""
         if self.get_attn or (self.use_cond2dec and self.nconds > 0):
             loss_rows = None
-        plan = _row_plan(self, src_mask, trg_mask, loss_rows, trg)
+        plan = _plan_ahead.finish() if _plan_ahead is not None else _row_plan(self, src_mask, trg_mask, loss_rows, trg)
         x, enc_attn = self.encoder.trunk(src, src_mask, econds, _keys=plan.enc_keys)
         z, mu, log_var = self.sampler(x)
         d = self.decoder(trg, z, src_mask, trg_mask, dconds, loss_rows, _compact_out=True, _plan=plan)

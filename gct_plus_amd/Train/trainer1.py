@@ -13,7 +13,7 @@ import torch
 import torch.distributed as dist
 
 from .. import engine
-from ..Model.forward_propagation1 import forward_propagation
+from ..Model.forward_propagation1 import forward_propagation, prefetch
 
 
 def KLAnnealer(epoch, KLA_ini_beta, KLA_inc_beta, KLA_beg_epoch):
@@ -77,7 +77,11 @@ def run_epoch(args, model, optimizer, dataloader, current_step, beta, LOG, train
                          f'TIME(s): {time() + cost_time:.1f}\tMODELTIME(s): {model_cost_time:.1f}\t'
                          f'UPDATETIME(s): {update_cost_time:.1f}')
 
-    for i, batch in enumerate(dataloader):
+    batches = iter(dataloader)
+    upcoming = next(batches, None)
+    i = -1
+    while upcoming is not None:
+        batch, upcoming, i = upcoming, next(batches, None), i + 1
         current_step += 1
         n_onebatch = batch['src'].size(0)
         model_cost_time -= time()
@@ -85,6 +89,10 @@ def run_epoch(args, model, optimizer, dataloader, current_step, beta, LOG, train
         # not compute them (engine.decoder_trunk_fwd; GCT_COMPACT_FWD=0 switches the shortcut off)
         preds_prop, preds_mol, mu, log_var, _ = forward_propagation[args.model_type](
             model, batch, args.pad_id, args.use_cond2dec, skip_ignored=True)[:5]
+        if upcoming is not None:
+            # the NEXT batch's masks and row maps are queued behind this forward: their read-back lands during this
+            # step's backward, so the next forward starts without a host synchronisation
+            prefetch(args.model_type, model, upcoming, args.pad_id, args.use_cond2dec, skip_ignored=True)
         model_cost_time += time()
         resolve()                # the previous step's scalars: already on the host
         ys_cond = batch['dconds'].unsqueeze(2).contiguous().view(-1, nprop, 1) if nprop > 0 else None
@@ -94,6 +102,16 @@ def run_epoch(args, model, optimizer, dataloader, current_step, beta, LOG, train
             optimizer.zero_grad(set_to_none=True)
         loss, RCE_mol, RCE_prop, KLD = loss_function(beta, preds_prop, preds_mol, ys_cond, ys_mol,
                                                      mu, log_var, args.use_cond2dec, args.pad_id)
+        scal = torch.stack([RCE_mol.detach(), KLD.detach(), loss.detach()])
+        host_scal = ev = None
+        if scal.is_cuda:
+            # the three scalars leave the device asynchronously, queued BEFORE the backward pass, and are read one step
+            # later (resolve(), after the next forward has been queued): the host never stops to wait for a loss; the
+            # history and the log lines are the same, one step late
+            host_scal = torch.empty(3, dtype=scal.dtype, pin_memory=True)
+            host_scal.copy_(scal, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
         if train:
             loss.backward()
             optimizer.step()
@@ -106,16 +124,8 @@ def run_epoch(args, model, optimizer, dataloader, current_step, beta, LOG, train
                 g['lr'] = lr
         current_lr = optimizer.param_groups[-1]['lr']
         n_samples += n_onebatch
-        scal = torch.stack([RCE_mol.detach(), KLD.detach(), loss.detach()])
-        if scal.is_cuda:
-            # the three scalars leave the device asynchronously and are READ one step later, after the next step's
-            # forward has been queued (its row plan is the step's one host synchronisation and completes behind this
-            # copy): the host never stops to wait for a loss, the history and the log lines are the same, one step late
-            host = torch.empty(3, dtype=scal.dtype, pin_memory=True)
-            host.copy_(scal, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            pending.append((i, n_onebatch, beta, current_lr, host, ev))
+        if host_scal is not None:
+            pending.append((i, n_onebatch, beta, current_lr, host_scal, ev))
         else:
             pending.append((i, n_onebatch, beta, current_lr, scal, None))
             resolve()

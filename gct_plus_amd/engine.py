@@ -87,8 +87,16 @@ class RowPlan:
     def build(cls, src_mask_u8, trg_mask_u8, loss_rows, B, Le, T, nc_lat, n_layers_enc, n_layers_dec):
         """src_mask_u8 [B, Le] (encoder keys, condition rows included); the decoder's memory mask is the same with nc_lat
         visible condition rows in front (use_cond2lat); loss_rows uint8 [B, T] or None."""
+        return cls.launch(src_mask_u8, trg_mask_u8, loss_rows, B, Le, T, nc_lat, n_layers_enc, n_layers_dec).finish()
+
+    @classmethod
+    def launch(cls, src_mask_u8, trg_mask_u8, loss_rows, B, Le, T, nc_lat, n_layers_enc, n_layers_dec):
+        """build() in two halves: the map kernels and ONE asynchronous read-back are queued here, .finish() of the
+        returned object waits for that read-back alone and returns the plan.  Queued a step ahead (between a step's
+        forward and its backward: Model/forward_propagation1.prefetch), the maps of the NEXT batch reach the host while
+        this step's backward runs, and the next forward starts without the host ever waiting for the device."""
         if torch.cuda.is_current_stream_capturing() or src_mask_u8 is None or src_mask_u8.numel() != B * Le:
-            return cls()
+            return _PendingPlan(None, None, None, None, 0, 0, 0)
         sm = src_mask_u8.view(B, Le)
         ek = ops.KeyRows(sm, B, Le) if (COMPACT_ENC_KV and n_layers_enc > 0) else None
         dk = None
@@ -104,8 +112,21 @@ class RowPlan:
         if (COMPACT_FWD and loss_rows is not None and trg_mask_u8 is not None and T <= 96 and Le + nc_lat <= 96
                 and n_layers_dec > 0):
             lr = ops.LiveRows.from_rows(loss_rows.reshape(B, T), B, T, trg_mask_u8)
-        ops.read_back(ek, dk, lr)                        # ONE synchronisation for all three
-        plan = cls(cls.usable_keys(ek, B * Le), cls.usable_keys(dk, B * (Le + nc_lat)), cls.usable_live(lr, B * T))
+        return _PendingPlan(ek, dk, lr, ops.PendingReadBack(ek, dk, lr),   # ONE read-back for all three
+                            B * Le, B * (Le + nc_lat), B * T)
+
+
+class _PendingPlan:
+    def __init__(self, ek, dk, lr, pending, rows_e, rows_d, rows_t):
+        self.ek, self.dk, self.lr, self.pending = ek, dk, lr, pending
+        self.rows = (rows_e, rows_d, rows_t)
+
+    def finish(self) -> "RowPlan":
+        if self.pending is None:
+            return RowPlan()
+        self.pending.finish()                            # the step's ONE host synchronisation
+        plan = RowPlan(RowPlan.usable_keys(self.ek, self.rows[0]), RowPlan.usable_keys(self.dk, self.rows[1]),
+                       RowPlan.usable_live(self.lr, self.rows[2]))
         if plan.live is not None:
             plan.live.fwd = True
         return plan

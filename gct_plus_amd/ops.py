@@ -559,6 +559,43 @@ def read_back(*objs):
         raise _lib.GctError(_SKIPPED_MSG.format(v[-1]))
 
 
+class PendingReadBack:
+    """read_back() in two halves: the constructor queues ONE asynchronous device->host copy of the maps' info records
+    (and of the skipped-row gradient counter) behind the kernels that wrote them and records an event; finish() waits
+    for that event only -- not for whatever was queued on the stream afterwards -- and fills the host side in.  The
+    trainer queues a batch's maps one step ahead (Model/forward_propagation1.prefetch), so finish() finds them done."""
+
+    def __init__(self, *objs):
+        seen, self.objs = set(), []
+        for o in objs:
+            if o is not None and o._host is None and id(o) not in seen:
+                seen.add(id(o))
+                self.objs.append(o)
+        self.host = self.ev = None
+        if self.objs:
+            dev = torch.cat([o.info for o in self.objs] + [skipped_row_gradients()])
+            self.host = torch.empty(dev.numel(), dtype=dev.dtype, pin_memory=True)
+            self.host.copy_(dev, non_blocking=True)
+            self.ev = torch.cuda.Event()
+            self.ev.record()
+
+    def finish(self):
+        if self.host is None:
+            return
+        import time
+        t0 = time.perf_counter()
+        self.ev.synchronize()
+        HOST_BLOCKED_S[0] += time.perf_counter() - t0
+        v = self.host.tolist()
+        self.host = None
+        for i, o in enumerate(self.objs):
+            if o._host is None:
+                o._fill_host(v[8 * i:8 * i + 8])
+        if v[-1] != 0:
+            skipped_row_gradients().zero_()
+            raise _lib.GctError(_SKIPPED_MSG.format(v[-1]))
+
+
 class KeyRows(LiveRows):
     """The compaction map of the KEY side of cross-attention, from a key-padding mask [B, Lk] (gct_key_rows): the
     padded rows of the encoder memory are masked keys, so their K / V projections (and dK / dV) need not exist.

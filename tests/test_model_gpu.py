@@ -831,6 +831,52 @@ def test_deferred_slab_reductions_give_identical_gradients(mtype, full, batch, m
     assert not ops._DEFER_TL.d["on"]
 
 
+@pytest.mark.parametrize("mtype", ["vaetf", "pscavaetf"])
+def test_announced_batch_gives_the_same_step(mtype):
+    """forward_propagation1.prefetch queues a batch's masks and row maps ahead of the forward that uses them (the
+    trainer: between the previous step's forward and its backward).  Same logits, loss and gradients, bit for bit, as the
+    un-announced call; an announcement for ANOTHER batch, or for a batch modified since, is dropped."""
+    from gct_plus_amd.Model import forward_propagation
+    from gct_plus_amd.Model.forward_propagation1 import prefetch
+    from gct_plus_amd.Train.trainer1 import loss_function
+    model = build(mtype, dropout=0.0).train()
+    nc = synthetic.n_conds(mtype)
+    b1 = to_dev(synthetic.make_dataset(9, max_len=24, model_type=mtype, seed=11))
+    b2 = to_dev(synthetic.make_dataset(9, max_len=24, model_type=mtype, seed=12))
+
+    def step(batch):
+        for p in model.parameters():
+            p.grad = None
+        prop, mol, mu, lv, _ = forward_propagation[mtype](model, batch, PAD, False, skip_ignored=True)
+        ys = batch["trg"][:, 1:].contiguous().view(-1)
+        ys_cond = batch["dconds"].unsqueeze(2).contiguous().view(-1, nc, 1) if nc else None
+        loss = loss_function(0.3, prop, mol, ys_cond, ys, mu, lv, False, PAD)[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        return mol.detach().clone(), loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()
+                                                              if p.grad is not None}
+
+    mu = forward_propagation[mtype](model, b1, PAD, False, skip_ignored=True)[2]
+    set_eps(model, torch.randn(mu.shape, generator=torch.Generator().manual_seed(3)).cuda())   # same noise every call
+    ref = step(b1)
+    prefetch(mtype, model, b1, PAD, False, skip_ignored=True)
+    assert model._gct_ahead is not None
+    got = step(b1)                                             # announced: uses the queued maps
+    assert model._gct_ahead is None
+    prefetch(mtype, model, b2, PAD, False, skip_ignored=True)
+    other = step(b1)                                           # announced another batch: dropped, built as usual
+    assert model._gct_ahead is None
+    prefetch(mtype, model, b1, PAD, False, skip_ignored=True)
+    b1["trg"][0, 3] = b1["trg"][0, 3]                          # an in-place write bumps the version: announcement stale
+    stale = step(b1)
+    live = (b1["trg"][:, 1:] != PAD)                           # (skipped rows hold no meaningful logits)
+    for out in (got, other, stale):
+        assert torch.equal(out[0][live], ref[0][live]) and torch.equal(out[1], ref[1])
+        assert out[2].keys() == ref[2].keys()
+        for k in ref[2]:
+            assert torch.equal(out[2][k], ref[2][k]), k
+
+
 def test_cond2dec_path_vs_reference(golden_dir):
     """HIP path with -use_cond2dec against the reference fixture: decoder cond tokens, [B,T+3,T+3]
     block mask, prop_fc head (N=1 GEMM) and the MSE term."""
